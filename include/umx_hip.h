@@ -1,0 +1,113 @@
+/*
+ * umx_hip.h -- C-ABI of the MI355X (gfx950) Open-Unmix segment-inference engine.
+ *
+ * Drop-in boundary for the reference's src/inference.cpp.  The reference has no plugin / FFI
+ * surface; the seam is the C++ call
+ *     std::vector<Eigen::MatrixXf> umxcpp::umx_inference(umx_model&, const Eigen::MatrixXf audio,
+ *         stft_buffers, std::array<lstm_data,4>& streaming_lstm_data);      (src/inference.hpp:20-23)
+ * made once per segment from umx.cpp:226-227, plus load_umx_model (src/model.hpp:58) that fills
+ * the model.  Each entry point below names what it replaces.  Plain pointers and sizes only:
+ * no Eigen, no torch types.  Every function returns an int status (UMX_OK == 0); the library
+ * never calls exit() (the reference exits or returns false: dsp.cpp:27-44, model.cpp:59-64).
+ *
+ * A (2,n) Eigen ColMajor MatrixXf is exactly n interleaved stereo frames, so "audio" and "out"
+ * buffers here are bit-identical to the reference's waveform matrices.
+ *
+ * Threading: one caller thread per context (as the reference: not re-entrant per stream state).
+ */
+#ifndef UMX_HIP_H
+#define UMX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMX_OK 0
+#define UMX_ERR_ARG 1     /* bad argument / shape (the reference: assert compiled out, or return false) */
+#define UMX_ERR_HIP 2     /* a HIP runtime call failed; see umx_hip_last_error */
+#define UMX_ERR_MODEL 3   /* missing / mis-shaped tensor (model.cpp:541-546, 582-591) */
+#define UMX_ERR_TIMEOUT 4 /* persistent LSTM kernel gave up waiting (bounded spin) */
+#define UMX_ERR_NODEVICE 5
+
+#define UMX_DTYPE_F32 0
+#define UMX_DTYPE_U8 1  /* model.cpp:578-619 load_single_matrix */
+#define UMX_DTYPE_U16 2 /* model.cpp:623-665 load_single_matrix_uint16 */
+
+/* flags of umx_hip_infer_segment* */
+#define UMX_FLAG_NO_WIENER 0x1      /* BASELINE config 2: mix-phase estimate only (wiener.cpp:96-109) */
+#define UMX_FLAG_SKIP_TARGET(t) (0x100 << (t)) /* BASELINE config 1 (vocals only = skip 0,1,2) */
+#define UMX_FLAG_LSTM_STEPWISE 0x10 /* one launch per timestep instead of the persistent kernel */
+#define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the mask tap (T x 4098 per target) for umx_hip_read_tap */
+
+/* One tensor of the ggml-style weight file, as stored (scripts/convert-umx-pth-to-ggml.py:146-160
+ * record = {scale, offset, n_dims, name_len, ne[], name, data}).  dtype F32 means `data` is already
+ * dequantised fp32 in PyTorch row-major order and scale/offset are ignored. */
+typedef struct umx_tensor_view
+{
+    const char *name; /* "fc1.weight", "lstm.weight_hh_l2_reverse", ... */
+    int target;       /* 0 = bass, 1 = drums, 2 = other, 3 = vocals (convert script :104) */
+    int dtype;        /* UMX_DTYPE_* */
+    int n_dims;
+    int ne[2];        /* PyTorch shape reversed, as in the file */
+    float scale, offset;
+    const void *data;
+} umx_tensor_view;
+
+typedef struct umx_hip_ctx umx_hip_ctx;
+
+/* Replaces the result of load_umx_model (model.cpp:42-574) living on the device: dequantises
+ * (q*scale+offset, model.cpp:610-616), re-lays the weights out for the kernels and uploads them.
+ * segment_samples = the stft_buffers size (umx.cpp:160: 60 s * 44100 = 2,646,000): every segment,
+ * also a shorter last one, is processed as T = segment_samples/1024+1 frames (dsp.cpp:214-217).
+ * Needs 4 x 43 tensors (model.cpp:240-539 name dispatch).  hidden_size % 128 == 0. */
+int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                   const umx_tensor_view *tensors, int n_tensors);
+void umx_hip_destroy(umx_hip_ctx *ctx);
+const char *umx_hip_last_error(const umx_hip_ctx *ctx); /* never NULL; also valid for ctx == NULL (create errors) */
+
+/* Streaming LSTM state = the h/c members of lstm_data (lstm.hpp:10-16), created zeroed once per
+ * track (umx.cpp:167-171, lstm.cpp:82) and carried across segments.
+ * Layout: [4 targets][3 layers][2 dirs][2: h, c][hidden/2] floats. */
+size_t umx_hip_stream_floats(const umx_hip_ctx *ctx);
+int umx_hip_stream_reset(umx_hip_ctx *ctx);                 /* create_lstm_data / umx_lstm_set_zero */
+int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst);  /* checkpoint / multi-GPU hand-off */
+int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src);
+
+/* umx_inference (inference.cpp:12-207): one segment -> 4 stems.
+ * audio: n interleaved stereo frames (2,n), 1 <= n <= segment_samples.  out[t]: (2,n) each.
+ * Host-pointer form: H2D + kernels + D2H, synchronous. */
+int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4],
+                          unsigned flags);
+/* Device-pointer form: buffers already in HBM (audio 2*n floats, out[t] 2*n floats each);
+ * asynchronous on the context's stream -- call umx_hip_sync before reading results. */
+int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
+                                 unsigned flags);
+int umx_hip_sync(umx_hip_ctx *ctx); /* also surfaces a persistent-kernel timeout as UMX_ERR_TIMEOUT */
+void *umx_hip_stream_handle(umx_hip_ctx *ctx); /* the hipStream_t all work is queued on */
+
+/* Geometry */
+int umx_hip_nb_frames(const umx_hip_ctx *ctx);       /* T = segment_samples/1024 + 1 (dsp.hpp:48) */
+int umx_hip_segment_samples(const umx_hip_ctx *ctx);
+int umx_hip_hidden(const umx_hip_ctx *ctx);
+
+/* Stage taps for parity tests (D2H copy of an intermediate of the LAST inferred segment).
+ * what: "spec" [2][T][2049] complex | "mix_mag" [2][T][2049] | "x" [T][2976] |
+ *       "fc1" [T][H] | "lstm" [T][H] | "mask" [T][4098] (needs UMX_FLAG_DEBUG_TAPS) |
+ *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex | "max_abs" [1]
+ * Returns the number of floats written (or needed when dst == NULL), < 0 on error. */
+long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst, size_t capacity_floats);
+
+/* Per-stage device time of the LAST segment, measured with hipEvents on the context's stream.
+ * names/ms are filled up to `cap` entries; returns the number of stages. */
+int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap);
+/* 1 if the LSTM layers of the last segment ran in the persistent (one launch per layer) kernel,
+ * 0 if the per-timestep driver was used (flag, unsupported hidden size, or grid not co-resident). */
+int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMX_HIP_H */

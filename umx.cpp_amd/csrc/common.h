@@ -1,0 +1,39 @@
+// common.h -- shared constants and helpers for the gfx950 UMX engine (device + host).
+// Compiled with -ffp-contract=off: elementwise epilogues keep the reference's operation order
+// (no silent FMA fusion); dot products / MFMA use explicit fused ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace umx
+{
+
+constexpr int NFFT = 4096;  // dsp.hpp:17
+constexpr int HOP = 1024;   // dsp.hpp:19
+constexpr int NBINS = 2049; // dsp.hpp:49
+constexpr int CROP = 1487;  // inference.cpp:55
+constexpr int NIN = 2974;   // inference.cpp:41
+constexpr int KX = 2976;    // NIN padded to a multiple of 32 (GEMM K tile)
+constexpr int NOUT = 4098;  // inference.cpp:53
+constexpr int NOUT_PAD = 4224; // NOUT padded to a multiple of 128 (GEMM N tile)
+constexpr int WIENER_BATCH = 200; // wiener.hpp:16
+constexpr float WIENER_EPS = 1e-10f;  // wiener.hpp:12
+constexpr float WIENER_SCALE = 10.0f; // wiener.hpp:13
+
+constexpr int LSTM_UNITS_PER_WG = 16; // hidden units (x4 gates = 64 gate columns) per workgroup
+constexpr int LSTM_THREADS = 512;     // 8 waves: wave w owns k-range [w*Hl/8, (w+1)*Hl/8)
+
+__host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+} // namespace umx
+
+#define UMX_HIP_CHECK(expr)                                                                      \
+    do                                                                                           \
+    {                                                                                            \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+        {                                                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                        \
+            return UMX_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)

@@ -1,0 +1,845 @@
+// engine.hip -- C-ABI implementation (include/umx_hip.h) of the gfx950 UMX segment engine.
+// Orchestrates one segment exactly like umx_inference (inference.cpp:12-207):
+//   stft -> |.| / crop+stack -> 4 x [fc1 bn tanh -> 3-layer BiLSTM -> fc2 bn relu -> fc3 bn scale
+//   relu -> mask*mix] -> Wiener EM -> 4 x istft
+// All kernels are queued on one HIP stream; the four targets run inside the same launches.
+#include "../../include/umx_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gemm_kernels.h"
+#include "lstm_kernels.h"
+#include "stft_kernels.h"
+#include "wiener_kernels.h"
+
+using namespace umx;
+
+namespace
+{
+std::string g_create_error = "";
+
+struct TargetBufs
+{
+    // weights
+    float *fc1_w = nullptr, *in_scale = nullptr, *in_mean = nullptr, *bn1[4] = {};
+    float *ih_w[3] = {}, *ih_b[3] = {};
+    float *fc2_w = nullptr, *bn2[4] = {};
+    float *fc3_w = nullptr, *bn3[4] = {}, *out_scale = nullptr, *out_mean = nullptr;
+    // activations
+    float *cat = nullptr, *la = nullptr, *lb = nullptr, *P = nullptr, *a2 = nullptr, *mag = nullptr,
+          *mask_dbg = nullptr;
+};
+
+enum
+{
+    ST_STFT = 0,
+    ST_FC1,
+    ST_IH0,
+    ST_LSTM0,
+    ST_IH1,
+    ST_LSTM1,
+    ST_IH2,
+    ST_LSTM2,
+    ST_FC2,
+    ST_FC3,
+    ST_WIENER,
+    ST_ISTFT,
+    ST_OLA,
+    ST_COUNT
+};
+const char *kStageNames[ST_COUNT] = {"stft",  "fc1", "lstm_ih0", "lstm_rec0", "lstm_ih1", "lstm_rec1", "lstm_ih2",
+                                     "lstm_rec2", "fc2", "fc3_mask", "wiener",  "istft",    "ola"};
+} // namespace
+
+struct umx_hip_ctx
+{
+    int device = 0, H = 0, Hl = 0, S = 0, N = 0, T = 0, Tp = 0, nbatch = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+    TargetBufs tb[4];
+    float *whh[3] = {}, *bhh[3] = {};
+    float *window = nullptr, *nw = nullptr;
+    float2 *tw1 = nullptr, *tw2 = nullptr;
+    float *audio_in = nullptr, *out_dev[4] = {};
+    float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
+    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr;
+    unsigned *maxabs = nullptr, *status = nullptr;
+    float *state = nullptr, *hbuf = nullptr;
+    unsigned long long *granules = nullptr;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    bool have_times = false, persistent_ok = true, last_persistent = false;
+    unsigned last_flags = 0;
+
+    void set_error(const std::string &s) { err = s; }
+
+    template <class T_> int dalloc(T_ **p, size_t count, bool zero = true)
+    {
+        void *q = nullptr;
+        UMX_HIP_CHECK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T_)));
+        allocs.push_back(q);
+        if (zero)
+            UMX_HIP_CHECK(hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T_)));
+        *p = reinterpret_cast<T_ *>(q);
+        return UMX_OK;
+    }
+    template <class T_> int upload(T_ **p, const std::vector<T_> &h)
+    {
+        int rc = dalloc(p, h.size(), false);
+        if (rc)
+            return rc;
+        UMX_HIP_CHECK(hipMemcpy(*p, h.data(), h.size() * sizeof(T_), hipMemcpyHostToDevice));
+        return UMX_OK;
+    }
+    int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors);
+    int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
+    int run_lstm_layer(int layer, const int *active, int nact, bool stepwise);
+};
+
+// ---------------------------------------------------------------- weights
+namespace
+{
+// model.cpp:578-665: q*scale+offset in fp32; F32 passes through
+bool dequant(const umx_tensor_view &tv, size_t expect, std::vector<float> &out)
+{
+    size_t nel = 1;
+    for (int i = 0; i < tv.n_dims; ++i)
+        nel *= (size_t)tv.ne[i];
+    if (nel != expect)
+        return false;
+    out.resize(nel);
+    if (tv.dtype == UMX_DTYPE_F32)
+        memcpy(out.data(), tv.data, nel * sizeof(float));
+    else if (tv.dtype == UMX_DTYPE_U8)
+    {
+        const uint8_t *q = static_cast<const uint8_t *>(tv.data);
+        for (size_t i = 0; i < nel; ++i)
+            out[i] = (float)q[i] * tv.scale + tv.offset;
+    }
+    else if (tv.dtype == UMX_DTYPE_U16)
+    {
+        const uint16_t *q = static_cast<const uint16_t *>(tv.data);
+        for (size_t i = 0; i < nel; ++i)
+            out[i] = (float)q[i] * tv.scale + tv.offset;
+    }
+    else
+        return false;
+    return true;
+}
+} // namespace
+
+int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors)
+{
+    if (hidden <= 0 || hidden % 128 != 0 || hidden > 2048)
+    {
+        set_error("hidden_size must be a positive multiple of 128 (<= 2048)");
+        return UMX_ERR_ARG;
+    }
+    if (segment_samples < NFFT)
+    {
+        set_error("segment_samples must be >= 4096");
+        return UMX_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        set_error("no HIP device available (this engine has no CPU fallback)");
+        return UMX_ERR_NODEVICE;
+    }
+    if (device_ < 0 || device_ >= ndev)
+    {
+        set_error("device index out of range");
+        return UMX_ERR_ARG;
+    }
+    device = device_;
+    UMX_HIP_CHECK(hipSetDevice(device));
+    UMX_HIP_CHECK(hipStreamCreate(&stream));
+    H = hidden;
+    Hl = H / 2;
+    S = Hl / LSTM_UNITS_PER_WG;
+    N = segment_samples;
+    T = N / HOP + 1; // dsp.hpp:48
+    Tp = round_up(T, GEMM_BM);
+    nbatch = (T + WIENER_BATCH - 1) / WIENER_BATCH;
+
+    // ---- index the tensor views by (target, name)
+    std::map<std::string, const umx_tensor_view *> idx[4];
+    for (int i = 0; i < n_tensors; ++i)
+    {
+        if (tensors[i].target < 0 || tensors[i].target > 3 || !tensors[i].name || !tensors[i].data)
+        {
+            set_error("tensor view with bad target / name / data");
+            return UMX_ERR_MODEL;
+        }
+        idx[tensors[i].target][tensors[i].name] = &tensors[i];
+    }
+    auto get = [&](int tg, const std::string &name, size_t expect, std::vector<float> &out) -> bool {
+        auto it = idx[tg].find(name);
+        if (it == idx[tg].end())
+        {
+            set_error("missing tensor '" + name + "' for target " + std::to_string(tg));
+            return false;
+        }
+        if (!dequant(*it->second, expect, out))
+        {
+            set_error("tensor '" + name + "' has wrong size in model (target " + std::to_string(tg) + ")");
+            return false;
+        }
+        return true;
+    };
+
+    const int G = 4 * Hl; // gate rows per direction
+    std::vector<float> whh_h[3], bhh_h[3];
+    for (int l = 0; l < 3; ++l)
+    {
+        whh_h[l].assign((size_t)8 * S * Hl * 64, 0.f);
+        bhh_h[l].assign((size_t)8 * S * 64, 0.f);
+    }
+    for (int tg = 0; tg < 4; ++tg)
+    {
+        TargetBufs &b = tb[tg];
+        std::vector<float> v, w;
+        // input / output scaling, duplicated per channel like model.cpp:240-290
+        if (!get(tg, "input_scale", CROP, v))
+            return UMX_ERR_MODEL;
+        w.assign(KX, 0.f);
+        for (int k = 0; k < NIN; ++k)
+            w[k] = v[k % CROP];
+        if (int rc = upload(&b.in_scale, w))
+            return rc;
+        if (!get(tg, "input_mean", CROP, v))
+            return UMX_ERR_MODEL;
+        w.assign(KX, 0.f);
+        for (int k = 0; k < NIN; ++k)
+            w[k] = v[k % CROP];
+        if (int rc = upload(&b.in_mean, w))
+            return rc;
+        if (!get(tg, "output_scale", NBINS, v))
+            return UMX_ERR_MODEL;
+        w.assign(NOUT_PAD, 0.f);
+        for (int k = 0; k < NOUT; ++k)
+            w[k] = v[k % NBINS];
+        if (int rc = upload(&b.out_scale, w))
+            return rc;
+        if (!get(tg, "output_mean", NBINS, v))
+            return UMX_ERR_MODEL;
+        w.assign(NOUT_PAD, 0.f);
+        for (int k = 0; k < NOUT; ++k)
+            w[k] = v[k % NBINS];
+        if (int rc = upload(&b.out_mean, w))
+            return rc;
+        // fc1 (H x 2974) -> (H x KX), zero K padding
+        if (!get(tg, "fc1.weight", (size_t)H * NIN, v))
+            return UMX_ERR_MODEL;
+        w.assign((size_t)H * KX, 0.f);
+        for (int o = 0; o < H; ++o)
+            memcpy(&w[(size_t)o * KX], &v[(size_t)o * NIN], sizeof(float) * NIN);
+        if (int rc = upload(&b.fc1_w, w))
+            return rc;
+        const char *bnn[4] = {"running_mean", "running_var", "weight", "bias"};
+        for (int k = 0; k < 4; ++k)
+        {
+            if (!get(tg, std::string("bn1.") + bnn[k], H, v))
+                return UMX_ERR_MODEL;
+            if (int rc = upload(&b.bn1[k], v))
+                return rc;
+            if (!get(tg, std::string("bn2.") + bnn[k], H, v))
+                return UMX_ERR_MODEL;
+            if (int rc = upload(&b.bn2[k], v))
+                return rc;
+            if (!get(tg, std::string("bn3.") + bnn[k], NOUT, v))
+                return UMX_ERR_MODEL;
+            w.assign(NOUT_PAD, k == 1 ? 1.f : 0.f); // padded running_var = 1: no 0/0 in dead columns
+            memcpy(w.data(), v.data(), sizeof(float) * NOUT);
+            if (int rc = upload(&b.bn3[k], w))
+                return rc;
+        }
+        if (!get(tg, "fc2.weight", (size_t)H * 2 * H, v))
+            return UMX_ERR_MODEL;
+        if (int rc = upload(&b.fc2_w, v))
+            return rc;
+        if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
+            return UMX_ERR_MODEL;
+        w.assign((size_t)NOUT_PAD * H, 0.f);
+        memcpy(w.data(), v.data(), sizeof(float) * (size_t)NOUT * H);
+        if (int rc = upload(&b.fc3_w, w))
+            return rc;
+        // LSTM: permute gate rows so a workgroup's 64 columns (g,u) are contiguous
+        for (int l = 0; l < 3; ++l)
+        {
+            std::vector<float> ihw((size_t)2 * G * H), ihb((size_t)2 * G);
+            for (int dir = 0; dir < 2; ++dir)
+            {
+                const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
+                std::vector<float> wih, whhv, bih, bhhv;
+                if (!get(tg, "lstm.weight_ih" + sfx, (size_t)G * H, wih) ||
+                    !get(tg, "lstm.weight_hh" + sfx, (size_t)G * Hl, whhv) ||
+                    !get(tg, "lstm.bias_ih" + sfx, G, bih) || !get(tg, "lstm.bias_hh" + sfx, G, bhhv))
+                    return UMX_ERR_MODEL;
+                const int chain = tg * 2 + dir;
+                for (int sl = 0; sl < S; ++sl)
+                    for (int g = 0; g < 4; ++g)
+                        for (int u = 0; u < 16; ++u)
+                        {
+                            const int row = g * Hl + sl * 16 + u; // PyTorch gate row (i|f|g|o blocks)
+                            const int col = g * 16 + u;
+                            const size_t n = (size_t)dir * G + (size_t)sl * 64 + col;
+                            memcpy(&ihw[n * H], &wih[(size_t)row * H], sizeof(float) * H);
+                            ihb[n] = bih[row];
+                            bhh_h[l][((size_t)chain * S + sl) * 64 + col] = bhhv[row];
+                            for (int k = 0; k < Hl; ++k)
+                                whh_h[l][(((size_t)chain * S + sl) * Hl + k) * 64 + col] = whhv[(size_t)row * Hl + k];
+                        }
+            }
+            if (int rc = upload(&b.ih_w[l], ihw))
+                return rc;
+            if (int rc = upload(&b.ih_b[l], ihb))
+                return rc;
+        }
+        // activations
+        if (int rc = dalloc(&b.cat, (size_t)Tp * 2 * H))
+            return rc;
+        if (int rc = dalloc(&b.la, (size_t)Tp * H))
+            return rc;
+        if (int rc = dalloc(&b.lb, (size_t)Tp * H))
+            return rc;
+        if (int rc = dalloc(&b.P, (size_t)Tp * 4 * H))
+            return rc;
+        if (int rc = dalloc(&b.a2, (size_t)Tp * H))
+            return rc;
+        if (int rc = dalloc(&b.mag, (size_t)2 * T * NBINS))
+            return rc;
+    }
+    for (int l = 0; l < 3; ++l)
+    {
+        if (int rc = upload(&whh[l], whh_h[l]))
+            return rc;
+        if (int rc = upload(&bhh[l], bhh_h[l]))
+            return rc;
+    }
+    // ---- tables: window (dsp.hpp:61-78, the reference's float PI), window sum-square
+    // (dsp.hpp:80-101, same accumulation order), FFT twiddles (rounded from double)
+    {
+        std::vector<float> w(NFFT);
+        static const float PI = 3.14159265359F;
+        const float floatN = (float)(NFFT + 1);
+        for (int n = 0; n < NFFT; ++n)
+            w[n] = 0.5F * (1.0F - cosf(2.0F * PI * (float)n / (floatN - 1)));
+        if (int rc = upload(&window, w))
+            return rc;
+        const size_t total = (size_t)NFFT + (size_t)HOP * (T - 1);
+        std::vector<float> nwh(total, 0.f);
+        for (int i = 0; i < T; ++i)
+        {
+            const size_t s0 = (size_t)i * HOP;
+            for (size_t j = s0; j < std::min(total, s0 + NFFT); ++j)
+                nwh[j] += w[j - s0] * w[j - s0];
+        }
+        if (int rc = upload(&nw, nwh))
+            return rc;
+        std::vector<float2> t1(256), t2(4096);
+        for (int r = 0; r < 16; ++r)
+            for (int k = 0; k < 16; ++k)
+            {
+                const double ph = -2.0 * M_PI * (double)(r * k) / 256.0;
+                t1[r * 16 + k] = make_float2((float)cos(ph), (float)sin(ph));
+            }
+        for (int r = 0; r < 16; ++r)
+            for (int j = 0; j < 256; ++j)
+            {
+                const double ph = -2.0 * M_PI * (double)(r * j) / 4096.0;
+                t2[r * 256 + j] = make_float2((float)cos(ph), (float)sin(ph));
+            }
+        if (int rc = upload(&tw1, t1))
+            return rc;
+        if (int rc = upload(&tw2, t2))
+            return rc;
+    }
+    // ---- segment buffers
+    if (int rc = dalloc(&audio_in, (size_t)2 * N))
+        return rc;
+    for (int s = 0; s < 4; ++s)
+        if (int rc = dalloc(&out_dev[s], (size_t)2 * N))
+            return rc;
+    if (int rc = dalloc(&spec, (size_t)2 * T * NBINS))
+        return rc;
+    if (int rc = dalloc(&mix_mag, (size_t)2 * T * NBINS))
+        return rc;
+    if (int rc = dalloc(&x, (size_t)Tp * KX))
+        return rc;
+    if (int rc = dalloc(&y, (size_t)4 * 2 * T * NBINS))
+        return rc;
+    if (int rc = dalloc(&frames, (size_t)4 * T * NFFT))
+        return rc;
+    if (int rc = dalloc(&wpart, (size_t)4 * nbatch * NBINS * 9))
+        return rc;
+    if (int rc = dalloc(&R, (size_t)4 * NBINS * 8))
+        return rc;
+    if (int rc = dalloc(&maxabs, 4))
+        return rc;
+    if (int rc = dalloc(&status, 4))
+        return rc;
+    if (int rc = dalloc(&state, (size_t)4 * 12 * Hl))
+        return rc;
+    if (int rc = dalloc(&hbuf, (size_t)2 * 8 * Hl))
+        return rc;
+    if (int rc = dalloc(&granules, (size_t)2 * 8 * Hl))
+        return rc;
+    for (int i = 0; i <= ST_COUNT; ++i)
+        UMX_HIP_CHECK(hipEventCreate(&ev[i]));
+    // dynamic LDS > 64 KiB must be opted into
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_IH>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    UMX_HIP_CHECK(hipDeviceSynchronize());
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- LSTM layer
+int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool stepwise)
+{
+    LstmArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = whh[layer];
+    a.bhh = bhh[layer];
+    a.state = state;
+    a.hbuf = hbuf;
+    a.granules = granules;
+    a.status = status;
+    a.Hl = Hl;
+    a.S = S;
+    a.T = T;
+    a.ldp = 4 * H;
+    a.layer = layer;
+    for (int i = 0; i < 4; ++i)
+    {
+        const TargetBufs &b = tb[i];
+        a.P[i] = b.P;
+        if (layer == 0)
+        {
+            a.out[i] = b.la;
+            a.ldo = H;
+            a.col0 = 0;
+        }
+        else if (layer == 1)
+        {
+            a.out[i] = b.lb;
+            a.ldo = H;
+            a.col0 = 0;
+        }
+        else
+        {
+            a.out[i] = b.cat; // inference.cpp:118-123 skip concat: lstm output -> right half of cat
+            a.ldo = 2 * H;
+            a.col0 = H;
+        }
+        a.tmap[i] = i < nact ? active[i] : 0;
+    }
+    const int nchains = 2 * nact;
+    const dim3 grid(S, nchains), block(LSTM_THREADS);
+    const int kpw = Hl / 8;
+    bool persistent = !stepwise && persistent_ok && (kpw == 8 || kpw == 16 || kpw == 32 || kpw == 64);
+    if (persistent)
+    {
+        UMX_HIP_CHECK(hipMemsetAsync(granules, 0, sizeof(unsigned long long) * 2 * 8 * Hl, stream));
+        void *kargs[] = {&a};
+        const void *fn = kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8>)
+                         : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16>)
+                         : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32>)
+                                     : reinterpret_cast<const void *>(lstm_persistent_kernel<64>);
+        // cooperative launch = the runtime verifies that the whole grid is co-resident, which the
+        // granule exchange needs; an over-size grid is refused instead of deadlocking
+        hipError_t e = hipLaunchCooperativeKernel(fn, grid, block, kargs, 0, stream);
+        if (e != hipSuccess)
+        {
+            (void)hipGetLastError();
+            persistent_ok = false; // e.g. fewer CUs than workgroups: use the per-step driver
+            persistent = false;
+        }
+    }
+    if (!persistent)
+    {
+        hipLaunchKernelGGL(lstm_state_to_hbuf, dim3(nchains), dim3(256), 0, stream, a, nchains);
+        for (int step = 0; step < T; ++step)
+            hipLaunchKernelGGL(lstm_step_kernel, grid, block, 0, stream, a, step);
+        hipLaunchKernelGGL(lstm_hbuf_to_state, dim3(nchains), dim3(256), 0, stream, a, nchains);
+    }
+    last_persistent = persistent;
+    UMX_HIP_CHECK(hipGetLastError());
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- one segment
+int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags)
+{
+    if (!audio_dev || n < 1 || n > N)
+    {
+        set_error("infer_segment: need 1 <= n <= segment_samples and non-null audio");
+        return UMX_ERR_ARG;
+    }
+    for (int s = 0; s < 4; ++s)
+        if (!out[s])
+        {
+            set_error("infer_segment: null output pointer");
+            return UMX_ERR_ARG;
+        }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    int active[4], nact = 0;
+    for (int tg = 0; tg < 4; ++tg)
+        if (!(flags & UMX_FLAG_SKIP_TARGET(tg)))
+            active[nact++] = tg;
+    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
+    if (dbg)
+        for (int tg = 0; tg < 4; ++tg)
+            if (!tb[tg].mask_dbg)
+                if (int rc = dalloc(&tb[tg].mask_dbg, (size_t)T * NOUT))
+                    return rc;
+    last_flags = flags;
+
+    UMX_HIP_CHECK(hipEventRecord(ev[ST_STFT], stream));
+    UMX_HIP_CHECK(hipMemsetAsync(maxabs, 0, sizeof(unsigned), stream));
+    hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, stream, audio_dev, n, N, T, window, tw1, tw2, spec,
+                       mix_mag, x, maxabs);
+    UMX_HIP_CHECK(hipEventRecord(ev[ST_FC1], stream));
+
+    auto launch_gemm = [&](int mode, int layer) {
+        GemmArgs g;
+        memset(&g, 0, sizeof g);
+        g.M = Tp;
+        g.T = T;
+        for (int i = 0; i < nact; ++i)
+        {
+            const TargetBufs &b = tb[active[i]];
+            GemmTarget &t = g.t[i];
+            switch (mode)
+            {
+            case G_FC1:
+                t.A = x; t.B = b.fc1_w; t.C = b.cat;
+                t.e0 = b.bn1[0]; t.e1 = b.bn1[1]; t.e2 = b.bn1[2]; t.e3 = b.bn1[3];
+                t.q0 = b.in_scale; t.q1 = b.in_mean;
+                g.N = H; g.K = KX; g.lda = KX; g.ldc = 2 * H;
+                break;
+            case G_IH:
+                t.A = layer == 0 ? b.cat : layer == 1 ? b.la : b.lb;
+                t.B = b.ih_w[layer]; t.C = b.P; t.e0 = b.ih_b[layer];
+                g.N = 4 * H; g.K = H; g.lda = layer == 0 ? 2 * H : H; g.ldc = 4 * H;
+                break;
+            case G_FC2:
+                t.A = b.cat; t.B = b.fc2_w; t.C = b.a2;
+                t.e0 = b.bn2[0]; t.e1 = b.bn2[1]; t.e2 = b.bn2[2]; t.e3 = b.bn2[3];
+                g.N = H; g.K = 2 * H; g.lda = 2 * H; g.ldc = H;
+                break;
+            default:
+                t.A = b.a2; t.B = b.fc3_w; t.C = b.mag;
+                t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
+                t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = mix_mag; t.dbg = dbg ? b.mask_dbg : nullptr;
+                g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0;
+                break;
+            }
+        }
+        const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
+        switch (mode)
+        {
+        case G_FC1: hipLaunchKernelGGL(gemm_tn_kernel<G_FC1>, grid, block, GEMM_LDS_BYTES, stream, g); break;
+        case G_IH: hipLaunchKernelGGL(gemm_tn_kernel<G_IH>, grid, block, GEMM_LDS_BYTES, stream, g); break;
+        case G_FC2: hipLaunchKernelGGL(gemm_tn_kernel<G_FC2>, grid, block, GEMM_LDS_BYTES, stream, g); break;
+        default: hipLaunchKernelGGL(gemm_tn_kernel<G_FC3>, grid, block, GEMM_LDS_BYTES, stream, g); break;
+        }
+    };
+
+    if (nact > 0)
+    {
+        launch_gemm(G_FC1, 0);
+        for (int layer = 0; layer < 3; ++layer)
+        {
+            UMX_HIP_CHECK(hipEventRecord(ev[ST_IH0 + 2 * layer], stream));
+            launch_gemm(G_IH, layer);
+            UMX_HIP_CHECK(hipEventRecord(ev[ST_LSTM0 + 2 * layer], stream));
+            if (int rc = run_lstm_layer(layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE))
+                return rc;
+        }
+        UMX_HIP_CHECK(hipEventRecord(ev[ST_FC2], stream));
+        launch_gemm(G_FC2, 0);
+        UMX_HIP_CHECK(hipEventRecord(ev[ST_FC3], stream));
+        launch_gemm(G_FC3, 0);
+    }
+    else
+    {
+        for (int k = ST_IH0; k <= ST_FC3; ++k)
+            UMX_HIP_CHECK(hipEventRecord(ev[k], stream));
+    }
+    for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
+        if (flags & UMX_FLAG_SKIP_TARGET(tg))
+            UMX_HIP_CHECK(hipMemsetAsync(tb[tg].mag, 0, sizeof(float) * 2 * T * NBINS, stream));
+    UMX_HIP_CHECK(hipEventRecord(ev[ST_WIENER], stream));
+    WienerMags wm;
+    for (int s = 0; s < 4; ++s)
+        wm.m[s] = tb[s].mag;
+    const int bt = (NBINS + 255) / 256;
+    if (flags & UMX_FLAG_NO_WIENER)
+    {
+        const size_t nel = (size_t)2 * T * NBINS;
+        hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, stream, spec, wm, T, y);
+    }
+    else
+    {
+        hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, stream, spec, wm, T, maxabs, wpart,
+                           nbatch);
+        hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, stream, wpart, nbatch, R);
+        hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, stream, spec, wm, T, maxabs, R, y);
+    }
+    UMX_HIP_CHECK(hipEventRecord(ev[ST_ISTFT], stream));
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, stream, y, T, window, nw, tw1, tw2, frames);
+    UMX_HIP_CHECK(hipEventRecord(ev[ST_OLA], stream));
+    OlaOut oo;
+    for (int s = 0; s < 4; ++s)
+        oo.p[s] = out[s];
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, stream, frames, T, n, oo);
+    UMX_HIP_CHECK(hipEventRecord(ev[ST_COUNT], stream));
+    UMX_HIP_CHECK(hipGetLastError());
+    have_times = true;
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- C-ABI
+extern "C"
+{
+
+int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                   const umx_tensor_view *tensors, int n_tensors)
+{
+    if (!out || !tensors)
+    {
+        g_create_error = "umx_hip_create: null argument";
+        return UMX_ERR_ARG;
+    }
+    *out = nullptr;
+    umx_hip_ctx *c = new umx_hip_ctx;
+    int rc = c->init(device, hidden_size, segment_samples, tensors, n_tensors);
+    if (rc != UMX_OK)
+    {
+        g_create_error = c->err;
+        umx_hip_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return UMX_OK;
+}
+
+void umx_hip_destroy(umx_hip_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->allocs)
+        (void)hipFree(p);
+    for (int i = 0; i <= ST_COUNT; ++i)
+        if (ctx->ev[i])
+            (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *umx_hip_last_error(const umx_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+size_t umx_hip_stream_floats(const umx_hip_ctx *ctx) { return ctx ? (size_t)4 * 12 * ctx->Hl : 0; }
+
+int umx_hip_stream_reset(umx_hip_ctx *ctx)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    hipError_t e = hipMemsetAsync(ctx->state, 0, sizeof(float) * 4 * 12 * ctx->Hl, ctx->stream);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    return UMX_OK;
+}
+
+int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst)
+{
+    if (!ctx || !host_dst)
+        return UMX_ERR_ARG;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(host_dst, ctx->state, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    return UMX_OK;
+}
+
+int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src)
+{
+    if (!ctx || !host_src)
+        return UMX_ERR_ARG;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(ctx->state, host_src, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    return UMX_OK;
+}
+
+int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
+                                 unsigned flags)
+{
+    if (!ctx || !out_dev)
+        return UMX_ERR_ARG;
+    return ctx->infer_device(audio_dev, n, out_dev, flags);
+}
+
+int umx_hip_sync(umx_hip_ctx *ctx)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    unsigned st = 0;
+    e = hipMemcpy(&st, ctx->status, sizeof st, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    if (st != 0)
+    {
+        ctx->set_error("persistent LSTM kernel timed out waiting for a hidden-state granule at step " +
+                       std::to_string(st - 1));
+        (void)hipMemset(ctx->status, 0, sizeof(unsigned));
+        ctx->persistent_ok = false;
+        return UMX_ERR_TIMEOUT;
+    }
+    return UMX_OK;
+}
+
+int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4], unsigned flags)
+{
+    if (!ctx || !audio_host || !out_host || n < 1 || n > ctx->N)
+    {
+        if (ctx)
+            ctx->set_error("infer_segment: bad arguments");
+        return UMX_ERR_ARG;
+    }
+    hipError_t e = hipMemcpyAsync(ctx->audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice,
+                                  ctx->stream);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    int rc = ctx->infer_device(ctx->audio_in, n, ctx->out_dev, flags);
+    if (rc)
+        return rc;
+    for (int s = 0; s < 4; ++s)
+    {
+        e = hipMemcpyAsync(out_host[s], ctx->out_dev[s], sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost,
+                           ctx->stream);
+        if (e != hipSuccess)
+        {
+            ctx->set_error(hipGetErrorString(e));
+            return UMX_ERR_HIP;
+        }
+    }
+    return umx_hip_sync(ctx);
+}
+
+void *umx_hip_stream_handle(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int umx_hip_nb_frames(const umx_hip_ctx *ctx) { return ctx ? ctx->T : 0; }
+int umx_hip_segment_samples(const umx_hip_ctx *ctx) { return ctx ? ctx->N : 0; }
+int umx_hip_hidden(const umx_hip_ctx *ctx) { return ctx ? ctx->H : 0; }
+
+long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst, size_t cap)
+{
+    if (!ctx || !what || target < 0 || target > 3)
+        return -1;
+    const std::string w = what;
+    const int T = ctx->T, H = ctx->H;
+    const void *src = nullptr;
+    size_t nfl = 0, src_ld = 0, rows = 0, cols = 0; // strided copy when src_ld != cols
+    if (w == "spec") { src = ctx->spec; nfl = (size_t)2 * 2 * T * NBINS; }
+    else if (w == "mix_mag") { src = ctx->mix_mag; nfl = (size_t)2 * T * NBINS; }
+    else if (w == "x") { src = ctx->x; nfl = (size_t)T * KX; }
+    else if (w == "fc1") { src = ctx->tb[target].cat; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
+    else if (w == "lstm") { src = ctx->tb[target].cat + H; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
+    else if (w == "mask") { src = ctx->tb[target].mask_dbg; nfl = (size_t)T * NOUT; }
+    else if (w == "target_mag") { src = ctx->tb[target].mag; nfl = (size_t)2 * T * NBINS; }
+    else if (w == "y") { src = ctx->y + (size_t)target * 2 * T * NBINS; nfl = (size_t)2 * 2 * T * NBINS; }
+    else if (w == "max_abs") { src = ctx->maxabs; nfl = 1; }
+    else return -1;
+    if (!src)
+        return -2;
+    if (!dst)
+        return (long)nfl;
+    if (cap < nfl)
+        return -3;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return -4;
+    hipError_t e;
+    if (rows)
+        e = hipMemcpy2D(dst, cols * sizeof(float), src, src_ld * sizeof(float), cols * sizeof(float), rows,
+                        hipMemcpyDeviceToHost);
+    else
+        e = hipMemcpy(dst, src, nfl * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return -4;
+    }
+    if (w == "max_abs")
+    {
+        unsigned bits;
+        memcpy(&bits, dst, 4);
+        float m;
+        memcpy(&m, &bits, 4);
+        dst[0] = std::max(1.0f, m / WIENER_SCALE);
+    }
+    return (long)nfl;
+}
+
+int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap)
+{
+    if (!ctx || !ctx->have_times)
+        return 0;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return 0;
+    int n = std::min(cap, (int)ST_COUNT);
+    for (int i = 0; i < n; ++i)
+    {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]);
+        if (names)
+            names[i] = kStageNames[i];
+        if (ms)
+            ms[i] = t;
+    }
+    return ST_COUNT;
+}
+
+int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx) { return ctx && ctx->last_persistent ? 1 : 0; }
+
+} // extern "C"

@@ -1,0 +1,213 @@
+// gemm_kernels.h -- fp32 MFMA GEMM with fused prologue/epilogue for the dense stack
+// (inference.cpp:75-99 fc1/bn1/tanh, lstm.cpp:132-135 W_ih x + b_ih for ALL frames at once,
+//  inference.cpp:127-140 fc2/bn2/relu, inference.cpp:143-183 fc3/bn3/scale/relu/mask).
+//
+//   C[M x N] = epilogue( prologue(A[M x K]) * B[N x K]^T )
+// A row-major (k contiguous); B is the weight in PyTorch (out, in) row-major layout, i.e. the
+// bytes of the ggml file as they are (model.cpp:578-619), zero-padded to N%128==0, K%32==0.
+// All four targets run in one launch (blockIdx.z = target).
+//
+// gfx950 mapping: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, exact fp32 FMA chain;
+// 157.3 TFLOP/s peak).  128x128x32 block tile, 4 waves as 2x2, each wave 2x2 MFMA tiles
+// (64 accumulator VGPRs).  LDS tiles are [row][k] with a 36-float row stride so that each lane's
+// ds_read_b128 of 4 consecutive k is conflict-free; lanes 0-31 take k = kb+{0..3}, lanes 32-63
+// take k = kb+{4..7}, and MFMA step s consumes element s of both operands, so A and B agree on
+// which k each (half-wave, step) pair means.  Global->LDS goes through registers (prefetch of
+// tile k+1 while tile k is multiplied), double-buffered LDS, one barrier per K tile.
+// Algorithmic flops per 60 s segment: 453.17 GFLOP.
+#pragma once
+#include "common.h"
+
+namespace umx
+{
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum GemmMode
+{
+    G_FC1 = 0, // A-prologue x*scale+mean; epilogue bn + tanh
+    G_IH = 1,  // epilogue + bias
+    G_FC2 = 2, // epilogue bn + relu
+    G_FC3 = 3  // epilogue bn, *out_scale + out_mean, relu, * mix_mag -> target magnitude [2][T][2049]
+};
+
+struct GemmTarget
+{
+    const float *A;
+    const float *B;
+    float *C;
+    const float *e0, *e1, *e2, *e3; // bn running_mean, running_var, weight, bias  | IH: e0 = bias
+    const float *q0, *q1;           // FC1: input scale, mean [KX]; FC3: output scale, mean [NOUT_PAD]
+    const float *aux;               // FC3: mix_mag
+    float *dbg;                     // FC3: optional mask tap [T][NOUT]
+};
+
+struct GemmArgs
+{
+    GemmTarget t[4];
+    int M, N, K, lda, ldc, T;
+};
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LD = 36;
+constexpr int GEMM_LDS_BYTES = 2 * 2 * 128 * GEMM_LD * 4; // 73,728
+
+__device__ __forceinline__ float4 scale_shift(float4 a, float4 sc, float4 mn)
+{
+    return make_float4(a.x * sc.x + mn.x, a.y * sc.y + mn.y, a.z * sc.z + mn.z, a.w * sc.w + mn.w);
+}
+
+template <int MODE> __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GemmTarget tg = args.t[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
+    const int K = args.K, lda = args.lda;
+
+    float *const sA0 = smem, *const sB0 = smem + 128 * GEMM_LD;
+    constexpr int BUF_STRIDE = 2 * 128 * GEMM_LD;
+
+    // global -> register staging: 4 float4 of A and 4 of B per thread per K tile
+    const int ld_row = tid >> 3, ld_kc = (tid & 7) * 4;
+    const float *gA = tg.A + (size_t)(m0 + ld_row) * lda + ld_kc;
+    const float *gB = tg.B + (size_t)(n0 + ld_row) * K + ld_kc;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+
+#define UMX_GLOAD(k0)                                                                                  \
+    {                                                                                                  \
+        ra0 = *reinterpret_cast<const float4 *>(gA + (size_t)(0) * lda + (k0));                        \
+        ra1 = *reinterpret_cast<const float4 *>(gA + (size_t)(32) * lda + (k0));                       \
+        ra2 = *reinterpret_cast<const float4 *>(gA + (size_t)(64) * lda + (k0));                       \
+        ra3 = *reinterpret_cast<const float4 *>(gA + (size_t)(96) * lda + (k0));                       \
+        rb0 = *reinterpret_cast<const float4 *>(gB + (size_t)(0) * K + (k0));                          \
+        rb1 = *reinterpret_cast<const float4 *>(gB + (size_t)(32) * K + (k0));                         \
+        rb2 = *reinterpret_cast<const float4 *>(gB + (size_t)(64) * K + (k0));                         \
+        rb3 = *reinterpret_cast<const float4 *>(gB + (size_t)(96) * K + (k0));                         \
+        if (MODE == G_FC1)                                                                             \
+        { /* inference.cpp:78-83: x*input_scale + input_mean (F8 order), fused into the A load */      \
+            const float4 sc = *reinterpret_cast<const float4 *>(tg.q0 + (k0) + ld_kc);                 \
+            const float4 mn = *reinterpret_cast<const float4 *>(tg.q1 + (k0) + ld_kc);                 \
+            ra0 = scale_shift(ra0, sc, mn);                                                            \
+            ra1 = scale_shift(ra1, sc, mn);                                                            \
+            ra2 = scale_shift(ra2, sc, mn);                                                            \
+            ra3 = scale_shift(ra3, sc, mn);                                                            \
+        }                                                                                              \
+    }
+#define UMX_SSTORE(buf)                                                                                \
+    {                                                                                                  \
+        float *a_ = sA0 + (buf)*BUF_STRIDE + ld_row * GEMM_LD + ld_kc;                                 \
+        float *b_ = sB0 + (buf)*BUF_STRIDE + ld_row * GEMM_LD + ld_kc;                                 \
+        *reinterpret_cast<float4 *>(a_) = ra0;                                                         \
+        *reinterpret_cast<float4 *>(a_ + 32 * GEMM_LD) = ra1;                                          \
+        *reinterpret_cast<float4 *>(a_ + 64 * GEMM_LD) = ra2;                                          \
+        *reinterpret_cast<float4 *>(a_ + 96 * GEMM_LD) = ra3;                                          \
+        *reinterpret_cast<float4 *>(b_) = rb0;                                                         \
+        *reinterpret_cast<float4 *>(b_ + 32 * GEMM_LD) = rb1;                                          \
+        *reinterpret_cast<float4 *>(b_ + 64 * GEMM_LD) = rb2;                                          \
+        *reinterpret_cast<float4 *>(b_ + 96 * GEMM_LD) = rb3;                                          \
+    }
+
+    floatx16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        acc00[r] = 0.f;
+        acc01[r] = 0.f;
+        acc10[r] = 0.f;
+        acc11[r] = 0.f;
+    }
+
+#define UMX_COMPUTE(buf)                                                                               \
+    {                                                                                                  \
+        const float *a = sA0 + (buf)*BUF_STRIDE + (wm * 64 + lr) * GEMM_LD + 4 * lh;                   \
+        const float *b = sB0 + (buf)*BUF_STRIDE + (wn * 64 + lr) * GEMM_LD + 4 * lh;                   \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                  \
+        {                                                                                              \
+            const float4 a0 = *reinterpret_cast<const float4 *>(a + g * 8);                            \
+            const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * GEMM_LD + g * 8);             \
+            const float4 b0 = *reinterpret_cast<const float4 *>(b + g * 8);                            \
+            const float4 b1 = *reinterpret_cast<const float4 *>(b + 32 * GEMM_LD + g * 8);             \
+            UMX_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                          \
+            UMX_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                          \
+            UMX_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                          \
+            UMX_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                          \
+        }                                                                                              \
+    }
+#define UMX_MFMA4(A0, A1, B0, B1)                                                                      \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc00, 0, 0, 0);                              \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B1, acc01, 0, 0, 0);                              \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B0, acc10, 0, 0, 0);                              \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(A1, B1, acc11, 0, 0, 0);
+
+    UMX_GLOAD(0)
+    UMX_SSTORE(0)
+    __syncthreads();
+    const int nk = K / GEMM_BK;
+    for (int kt = 0; kt < nk - 1; ++kt)
+    {
+        const int cur = kt & 1;
+        UMX_GLOAD((kt + 1) * GEMM_BK)
+        UMX_COMPUTE(cur)
+        UMX_SSTORE(cur ^ 1)
+        __syncthreads();
+    }
+    UMX_COMPUTE((nk - 1) & 1)
+#undef UMX_GLOAD
+#undef UMX_SSTORE
+#undef UMX_COMPUTE
+#undef UMX_MFMA4
+
+    // epilogue: lane owns column n, rows (r&3) + 8*(r>>2) + 4*lh of each 32x32 tile
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+    {
+        const int n = n0 + wn * 64 + ni * 32 + lr;
+        float rm = 0.f, sd = 1.f, gw = 1.f, gb = 0.f, osc = 1.f, omn = 0.f;
+        if (MODE == G_IH)
+            gb = tg.e0[n];
+        else
+        {
+            rm = tg.e0[n];
+            sd = sqrtf(tg.e1[n] + 1e-5f); // inference.cpp:94-95
+            gw = tg.e2[n];
+            gb = tg.e3[n];
+        }
+        if (MODE == G_FC3)
+        {
+            osc = tg.q0[n];
+            omn = tg.q1[n];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+            {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float y = mi == 0 ? (ni == 0 ? acc00[r] : acc01[r]) : (ni == 0 ? acc10[r] : acc11[r]);
+                if (MODE == G_IH)
+                {
+                    tg.C[(size_t)m * args.ldc + n] = y + gb; // lstm.cpp:132-135: W_ih x + b_ih
+                }
+                else
+                {
+                    y = ((y - rm) / sd) * gw + gb; // batchnorm, inference.cpp:93-97 order
+                    if (MODE == G_FC1)
+                        tg.C[(size_t)m * args.ldc + n] = tanhf(y);
+                    else if (MODE == G_FC2)
+                        tg.C[(size_t)m * args.ldc + n] = fmaxf(y, 0.f);
+                    else if (n < NOUT && m < args.T)
+                    {
+                        y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
+                        if (tg.dbg)
+                            tg.dbg[(size_t)m * NOUT + n] = y;
+                        const int c = n >= NBINS ? 1 : 0, b = n - c * NBINS;
+                        const size_t idx = ((size_t)c * args.T + m) * NBINS + b;
+                        tg.C[idx] = y * tg.aux[idx]; // inference.cpp:175-183
+                    }
+                }
+            }
+    }
+}
+
+} // namespace umx

@@ -1,0 +1,156 @@
+// stft_kernels.h -- STFT / iSTFT kernels (replace dsp.cpp:109-258 + inference.cpp:29,52-68).
+//
+// HBM layouts (b fastest, so a wave touches consecutive bins):
+//   spec    float2 [2][T][2049]      (reference: Eigen ColMajor (2,T,2049), c fastest)
+//   mix_mag float  [2][T][2049]
+//   x       float  [Tp][KX]          row t = [ |L|[0:1487] | |R|[0:1487] | 0 0 ]  (inference.cpp:58-68)
+//   y       float2 [4][2][T][2049]   per-source complex spectrograms
+//   frames  float2 [4][T][4096]      (.x = left, .y = right) windowed + normalised iFFT frames
+// Algorithmic HBM bytes per 60 s segment (T = 2584):
+//   stft : read 21.2 MB audio; write 84.7 (spec) + 42.4 (mag) + 30.8 (x) = 157.9 MB
+//   istft: read 338.8 MB (y), write 338.7 MB (frames); ola: read 338.7 MB, write 84.7 MB
+#pragma once
+#include "fft4096.h"
+
+namespace umx
+{
+
+// One workgroup per frame; both channels in one complex FFT.
+__global__ __launch_bounds__(256) void stft_kernel(const float *__restrict__ audio, int n, int N, int T,
+                                                   const float *__restrict__ window,
+                                                   const float2 *__restrict__ tw1,
+                                                   const float2 *__restrict__ tw2,
+                                                   float2 *__restrict__ spec, float *__restrict__ mix_mag,
+                                                   float *__restrict__ x, unsigned *__restrict__ maxabs_bits)
+{
+    __shared__ float2 buf[FFT_LDS_ELEMS];
+    __shared__ float red[4];
+    const int f = blockIdx.x, j = threadIdx.x;
+    const float2 *a2 = reinterpret_cast<const float2 *>(audio);
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        const int i = j + 256 * r;
+        const int p = f * HOP + i; // index into the reference's padded buffer (size N + 4096)
+        int d;                     // index into the chunk; pad_signal dsp.cpp:109-128 (symmetric)
+        if (p < NFFT / 2)
+            d = NFFT / 2 - 1 - p;
+        else if (p < N + NFFT / 2)
+            d = p - NFFT / 2;
+        else
+            d = N - 1 - (p - (N + NFFT / 2));
+        float2 s = (d < n) ? a2[d] : make_float2(0.f, 0.f); // short chunk: rest of buffer is zeros
+        const float w = window[i];
+        v[r] = make_float2(s.x * w, s.y * w); // dsp.cpp:220-225
+    }
+    fft4096<false>(v, buf, tw1, tw2);
+    float lmax = 0.f;
+    for (int k = j; k <= NFFT / 2; k += 256)
+    {
+        const float2 zk = buf[fft_pad(k)];
+        const float2 zn = cconj(buf[fft_pad((NFFT - k) & (NFFT - 1))]);
+        const float2 sL = make_float2((zk.x + zn.x) * 0.5f, (zk.y + zn.y) * 0.5f);
+        const float2 dd = csub(zk, zn);
+        const float2 sR = make_float2(dd.y * 0.5f, -dd.x * 0.5f); // (zk - zn) / (2i)
+        const size_t iL = ((size_t)0 * T + f) * NBINS + k, iR = ((size_t)1 * T + f) * NBINS + k;
+        spec[iL] = sL;
+        spec[iR] = sR;
+        const float mL = hypotf(sL.x, sL.y), mR = hypotf(sR.x, sR.y); // inference.cpp:29 abs()
+        mix_mag[iL] = mL;
+        mix_mag[iR] = mR;
+        if (k < CROP)
+        {
+            x[(size_t)f * KX + k] = mL;
+            x[(size_t)f * KX + CROP + k] = mR;
+        }
+        // wiener.cpp:37-52 find_max_abs uses sqrt(norm(z))
+        lmax = fmaxf(lmax, fmaxf(sqrtf(sL.x * sL.x + sL.y * sL.y), sqrtf(sR.x * sR.x + sR.y * sR.y)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((j & 63) == 0)
+        red[j >> 6] = lmax;
+    __syncthreads();
+    if (j == 0)
+    {
+        float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        atomicMax(maxabs_bits, __float_as_uint(m)); // non-negative floats order like uints
+    }
+}
+
+// grid (T, 4 sources).  Unscaled inverse real FFT of both channels at once, then the reference's
+// per-sample weight  frame*w * 1.0f / 4096 / (nw + 1e-8f)  (dsp.cpp:248-256, same op order).
+__global__ __launch_bounds__(256) void istft_frames_kernel(const float2 *__restrict__ y, int T,
+                                                           const float *__restrict__ window,
+                                                           const float *__restrict__ nw,
+                                                           const float2 *__restrict__ tw1,
+                                                           const float2 *__restrict__ tw2,
+                                                           float2 *__restrict__ frames)
+{
+    __shared__ float2 buf[FFT_LDS_ELEMS];
+    const int f = blockIdx.x, src = blockIdx.y, j = threadIdx.x;
+    const float2 *yL = y + (((size_t)src * 2 + 0) * T + f) * NBINS;
+    const float2 *yR = y + (((size_t)src * 2 + 1) * T + f) * NBINS;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        const int i = j + 256 * r;
+        if (i <= NFFT / 2)
+        {
+            float2 a = yL[i], b = yR[i];
+            if (i == 0 || i == NFFT / 2) // a real inverse FFT ignores Im of DC / Nyquist
+            {
+                a.y = 0.f;
+                b.y = 0.f;
+            }
+            v[r] = make_float2(a.x - b.y, a.y + b.x); // a + i b
+        }
+        else
+        {
+            const float2 a = yL[NFFT - i], b = yR[NFFT - i];
+            v[r] = make_float2(a.x + b.y, b.x - a.y); // conj(a) + i conj(b)
+        }
+    }
+    fft4096<true>(v, buf, tw1, tw2);
+    float2 *dst = frames + ((size_t)src * T + f) * NFFT;
+    const size_t start = (size_t)f * HOP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        const int i = j + 256 * r;
+        const float2 z = buf[fft_pad(i)];
+        const float w = window[i];
+        const float den = nw[start + i] + 1e-8f;
+        dst[i] = make_float2(z.x * w * 1.0f / float(NFFT) / den, z.y * w * 1.0f / float(NFFT) / den);
+    }
+}
+
+// Overlap-add in ascending frame order (the reference's fp32 summation order, dsp.cpp:237-257)
+// and crop [2048, 2048+n) (dsp.cpp:203-205).  out: 4 x (2,n) interleaved.  grid (ceil(n/256), 4).
+struct OlaOut
+{
+    float *p[4];
+};
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float2 *__restrict__ frames, int T, int n,
+                                                        OlaOut out)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
+    if (s >= n)
+        return;
+    const int p = s + NFFT / 2;
+    const int f_hi = min(T - 1, p / HOP);
+    const int f_lo = p >= NFFT ? (p - NFFT) / HOP + 1 : 0;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int f = f_lo; f <= f_hi; ++f)
+    {
+        const float2 c = frames[((size_t)src * T + f) * NFFT + (p - f * HOP)];
+        acc.x += c.x;
+        acc.y += c.y;
+    }
+    reinterpret_cast<float2 *>(out.p[src])[s] = acc;
+}
+
+} // namespace umx
