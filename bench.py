@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- realtime factor of UMX-L 4-stem separation on 60 s segments (BASELINE.json metric).
+
+A "step" = one pass of the hot path (umx_inference, inference.cpp:12-207) over one synthetic 60 s
+stereo segment: STFT -> 4 x [fc1/bn/tanh -> 3-layer BiLSTM -> fc2 -> fc3 -> mask] -> Wiener EM ->
+4 x iSTFT, with the input already resident in HBM and the 4 stems left in HBM.  Consecutive steps
+are consecutive segments of one track: the streaming LSTM state carries over (umx.cpp:167-171).
+The default workload is BASELINE config 3 (4 stems + Wiener, the full umx_inference); --no-wiener
+gives config 2.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank separates its own
+independent segments (weak scaling; the path shards by segment/track, no data-path collective);
+barrier + synchronize on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as ge  # noqa: E402
+
+SEG = 60 * 44100
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def algorithmic_work(T, H, wiener=True):
+    """Per-segment algorithmic flops / bytes per stage."""
+    NB, KX, NOUT = 2049, 2974, 4098
+    gemm = {
+        "fc1": 2.0 * T * KX * H * 4,
+        "lstm_ih": 2.0 * T * H * (4 * H) * 4,          # per layer, both directions, 4 targets
+        "fc2": 2.0 * T * (2 * H) * H * 4,
+        "fc3_mask": 2.0 * T * H * NOUT * 4,
+    }
+    rec = 2.0 * T * (H // 2) * (2 * H) * 2 * 4         # per layer: W_hh.h, 2 dirs, 4 targets
+    bytes_ = {
+        "stft": 4.0 * (2 * T * 1024 + 2 * T * NB * 2 + 2 * T * NB + T * 2976),
+        "wiener": 4.0 * (4 * (2 * T * NB * 3) + (2 * T * NB * 2 + 4 * 2 * T * NB) + 4 * 2 * T * NB * 2) if wiener
+        else 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * 2 * T * NB * 2),
+        "istft": 4.0 * (4 * 2 * T * NB * 2 + 4 * T * 4096 * 2),
+        "ola": 4.0 * (4 * T * 4096 * 2 + 4 * 2 * T * 1024),
+    }
+    return gemm, rec, bytes_
+
+
+def cpu_baseline(pkg, hidden, weights_path, seconds_audio=6.0, threads=None):
+    """Reference-equivalent CPU path (oracle, reference flag set -O3 -march=native -ffast-math) on a
+    bounded sample of the same workload: the first `seconds_audio` of the synthetic track as one
+    segment (same per-frame cost as a 60 s segment; LSTM state zero).  NOT the Eigen binary."""
+    po = ge.load_oracle()
+    threads = threads or os.cpu_count()
+    po.set_num_threads(threads, fast=True)
+    om = po.Model.load(weights_path, fast=True)
+    n = int(seconds_audio * 44100)
+    wave = pkg.ggml.synth_audio(n, seed=0)
+    t0 = time.time()
+    po.umx_inference(om, wave)
+    dt = time.time() - t0
+    return {"value": round(seconds_audio / dt, 4), "unit": "x realtime (audio-sec / wall-sec)", "cores": threads,
+            "kind": "port",
+            "sample": f"first {seconds_audio:g} s of the synthetic track as one segment ({n // 1024 + 1} frames), "
+                      f"4 stems + Wiener, {dt:.1f} s wall; Eigen-equivalent restatement (oracle/, -O3 -march=native "
+                      f"-ffast-math -fopenmp, per-timestep GEMV LSTM), not the Eigen binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--hidden", type=int, default=1024)
+    ap.add_argument("--segment-samples", type=int, default=SEG)
+    ap.add_argument("--no-wiener", action="store_true")
+    ap.add_argument("--stepwise-lstm", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = ge.load_package()
+    H, N = args.hidden, args.segment_samples
+    # synthetic UMX-L-shaped weights in the reference's file format (u8/u16 + scale/offset); every
+    # rank writes its own copy (seeded, identical) to avoid a file-system race
+    tmpdir = tempfile.mkdtemp(prefix=f"umx_bench_r{rank}_")
+    wpath = os.path.join(tmpdir, "ggml-model-synth-u8.bin")
+    pkg.ggml.write_model(wpath, pkg.ggml.synth_weights(H, seed=0), H, compress=False)
+    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank)
+    T = eng.T
+
+    wave = pkg.ggml.synth_audio(N, seed=rank)  # each rank: its own track
+    audio = torch.from_numpy(np.ascontiguousarray(wave.T).ravel()).to(dev)  # (2,n) interleaved, in HBM
+    outs = [torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)]
+    flags = (pkg.FLAG_NO_WIENER if args.no_wiener else 0) | (pkg.FLAG_LSTM_STEPWISE if args.stepwise_lstm else 0)
+    ptrs = [o.data_ptr() for o in outs]
+
+    def step():
+        eng.infer_segment_device(audio.data_ptr(), N, ptrs, flags)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stage_acc = {}
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # per-stage device time of the last segment, from hipEvents on the engine's own stream
+    stage_ms = eng.stage_times()
+    finite = bool(all(torch.isfinite(o).all().item() for o in outs))
+
+    if rank == 0:
+        seg_sec = N / 44100.0
+        value = world * args.steps * seg_sec / dt
+        gemm, rec, byt = algorithmic_work(T, H, not args.no_wiener)
+        lstm_ms = sum(stage_ms.get(f"lstm_rec{l}", 0.0) for l in range(3))
+        gemm_ms = stage_ms.get("fc1", 0) + stage_ms.get("fc2", 0) + stage_ms.get("fc3_mask", 0) + \
+            sum(stage_ms.get(f"lstm_ih{l}", 0.0) for l in range(3))
+        gemm_flops = gemm["fc1"] + 3 * gemm["lstm_ih"] + gemm["fc2"] + gemm["fc3_mask"]
+        # dominant kernel by device time
+        if lstm_ms >= gemm_ms:
+            # serial recurrence: fp32 FMA work priced against the f32 peak (it is latency-bound: 3*T
+            # dependent steps; DESIGN.md gives the step-latency view of the same number)
+            ach = 3 * rec / (lstm_ms * 1e-3) / 1e12
+            roofline = {"kernel": "lstm_persistent_kernel" if eng.lstm_was_persistent() else "lstm_step_kernel",
+                        "bound": "mfma", "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(ach / F32_MFMA_PEAK_TF, 5), "traffic": None,
+                        "us_per_step": round(lstm_ms * 1e3 / (3 * T), 3), "serial_steps": 3 * T}
+        else:
+            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
+            roofline = {"kernel": "gemm_tn_kernel", "bound": "mfma", "achieved": round(ach, 3),
+                        "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 5),
+                        "traffic": None}
+        gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        stream_ms = sum(stage_ms.get(k, 0.0) for k in ("stft", "wiener", "istft", "ola"))
+        stream_gbs = sum(byt.values()) / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else None
+        line = {
+            "metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg",
+            "value": round(value, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("UMX-L single 60 s segment, 4 stems" +
+                                    (" (no Wiener)" if args.no_wiener else " + multichannel Wiener EM") +
+                                    " on 1 MI355X per rank; seeded synthetic 44.1 kHz stereo, synthetic "
+                                    "UMX-L-shaped u8/u16 ggml weights"),
+                       "hidden": H, "segment_samples": N, "frames": T, "stems": 4,
+                       "lstm": "persistent" if eng.lstm_was_persistent() else "stepwise",
+                       "sharding": f"{world} independent segments (one per rank)"},
+            "roofline": roofline,
+            "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "gemm_tflops": round(gemm_tf, 2) if gemm_tf else None,
+            "streaming_gbs": round(stream_gbs, 1) if stream_gbs else None,
+            "outputs_finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(pkg, H, wpath, args.cpu_sample_seconds)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
