@@ -1,0 +1,88 @@
+/*
+ * umx_host.h -- C-ABI of the C++17 host side that surrounds the segment engine: the ggml weight
+ * loader, WAV in/out and the segmented-apply drivers.  Pure host code (no HIP): it is what the
+ * reference keeps in src/model.cpp, src/dsp.cpp (load_audio / write_audio_file) and umx.cpp, and
+ * it talks to the device only through include/umx_hip.h.
+ *
+ * Every function returns an int status (0 = ok) and never exits the process; `err`, when given,
+ * points to a buffer of at least UMX_ERRLEN bytes that receives a message.
+ */
+#ifndef UMX_HOST_H
+#define UMX_HOST_H
+
+#include "umx_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMX_ERRLEN 256
+#define UMX_HOST_ERR_IO 10      /* cannot open / read / write a file */
+#define UMX_HOST_ERR_FORMAT 11  /* bad magic, truncated record, unknown tensor name, wrong shape */
+#define UMX_HOST_ERR_AUDIO 12   /* unsupported sample rate / channel count / encoding */
+#define UMX_HOST_ERR_BACKEND 13 /* the segment backend returned an error */
+
+#define UMX_SAMPLE_RATE 44100          /* dsp.hpp:16 SUPPORTED_SAMPLE_RATE */
+#define UMX_SEGMENT_SAMPLES 2646000    /* inference.hpp:13 SEGMENT_LEN_SECS * 44100 (umx.cpp:156-157) */
+#define UMX_MAX_SHIFT_SAMPLES 22050    /* inference.hpp:14 MAX_SHIFT_SECS * 44100 (umx.cpp:112-113) */
+
+/* ---- weight file: replaces load_umx_model (src/model.cpp:42-574, declared src/model.hpp:58).
+ * Reads a gzip'ed (or plain) ggml-style file entirely in memory (the reference inflates to
+ * ./temp.decompressed in 128-byte reads, model.cpp:56-84) and keeps every tensor as stored
+ * (u8/u16 + scale/offset); dequantisation happens where the tensor is consumed. */
+typedef struct umx_model umx_model;
+int umx_model_load(const char *path, umx_model **out, char *err);
+void umx_model_free(umx_model *m);
+int umx_model_hidden(const umx_model *m);                      /* model.cpp:109-114 */
+int umx_model_n_tensors(const umx_model *m);                   /* 172 for a complete file (README.md:191) */
+const umx_tensor_view *umx_model_views(const umx_model *m);    /* n_tensors entries, valid while m lives */
+size_t umx_model_data_bytes(const umx_model *m);               /* the "131.93 MB" of model.cpp:566-568 */
+float umx_model_load_progress(const umx_model *m);             /* model.hpp:54, 1.0 when loaded */
+/* fp32 copy of one tensor, dequantised exactly like model.cpp:610-616 / 656-662; returns numel or <0 */
+long umx_model_dequantize(const umx_model *m, int target, const char *name, float *dst, size_t capacity);
+
+/* ---- audio files: replaces load_audio / write_audio_file (src/dsp.cpp:18-101, libnyquist).
+ * load: RIFF/WAVE PCM 16/24/32-bit int or 32-bit float (plain or WAVE_FORMAT_EXTENSIBLE), mono or
+ * stereo, 44100 Hz only (dsp.cpp:27-33 exits on another rate; here UMX_HOST_ERR_AUDIO).  Returns a
+ * malloc'ed (2,n) interleaved stereo buffer, mono duplicated into both channels (dsp.cpp:52-60). */
+int umx_wav_load(const char *path, float **audio_out, int *n_frames_out, int *channels_in_file, char *err);
+void umx_wav_free(float *audio);
+/* write: stereo 32-bit IEEE float WAV, 44100 Hz (dsp.cpp:97-99 {channels, PCM_FLT, ...}) */
+int umx_wav_write_f32(const char *path, const float *audio, int n_frames, char *err);
+
+/* ---- segmented apply: replaces split_inference / shift_inference (umx.cpp:99-295).
+ * The backend is the per-segment call (umx_inference, umx.cpp:226-227): audio (2,n) -> out[4] (2,n);
+ * reset is called once per track where the reference creates its 4 zeroed lstm_data
+ * (umx.cpp:167-171).  host/umx_cli.cpp adapts a umx_hip_ctx to this; tests plug the oracle. */
+typedef int (*umx_segment_fn)(void *user, const float *audio, int n, float *const out[4]);
+typedef int (*umx_reset_fn)(void *user);
+typedef struct umx_backend
+{
+    umx_segment_fn segment;
+    umx_reset_fn reset; /* may be NULL */
+    void *user;
+} umx_backend;
+
+/* 60 s segments, stride = int(0.75 * segment) (umx.cpp:181), triangular weights (umx.cpp:197-206),
+ * weighted overlap-add and division by the weight sum (umx.cpp:234-273).  Deliberate deviation:
+ * sum_weight is fully zero-initialised (the reference writes it out of bounds / leaves it
+ * uninitialised for tracks < 29.6 s, umx.cpp:197-204 -- SURVEY F4).  progress (optional) receives
+ * the reference's inference_progress value after each segment (umx.cpp:229). */
+int umx_split_inference(const umx_backend *be, const float *audio, int length, int segment_samples,
+                        float *const out[4], void (*progress)(float, void *), void *progress_user, char *err);
+/* umx.cpp:99-150: delay by `offset` inside a zero buffer of length+22050-offset samples, split, trim.
+ * offset < 0 -> rand() % 22050 like the reference (unseeded glibc rand(): 4033). */
+int umx_shift_inference(const umx_backend *be, const float *audio, int length, int segment_samples,
+                        int offset, float *const out[4], void (*progress)(float, void *), void *progress_user,
+                        char *err);
+
+/* Plan of a track: the (offset, length) of every segment split_inference will run (umx.cpp:214-218),
+ * used by the multi-GPU scheduler.  Returns the number of segments; fills up to cap entries. */
+int umx_segment_plan(int length, int segment_samples, int *offsets, int *lengths, int cap);
+/* The triangular transition weight of sample k of a chunk (umx.cpp:197-206, 246). */
+float umx_transition_weight(int k, int chunk_len, int segment_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMX_HOST_H */

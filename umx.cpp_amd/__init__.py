@@ -223,3 +223,203 @@ class Engine:
         ms = (C.c_float * 32)()
         n = self.lib.umx_hip_stage_times(self.h, names, ms, 32)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+
+# ------------------------------------------------------------------ C++17 host library (umx_host.h)
+HOST_SYMBOLS = ["umx_model_load", "umx_model_free", "umx_model_hidden", "umx_model_n_tensors", "umx_model_views",
+                "umx_model_data_bytes", "umx_model_load_progress", "umx_model_dequantize", "umx_wav_load",
+                "umx_wav_free", "umx_wav_write_f32", "umx_split_inference", "umx_shift_inference",
+                "umx_segment_plan", "umx_transition_weight"]
+
+SEGMENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int, C.POINTER(_fp))
+RESET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_float, C.c_void_p)
+
+
+class Backend(C.Structure):
+    """include/umx_host.h: umx_backend"""
+    _fields_ = [("segment", SEGMENT_FN), ("reset", RESET_FN), ("user", C.c_void_p)]
+
+
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is not None:
+        return _host
+    path = HERE / "libumx_host.so"
+    if not path.exists():
+        raise ImportError(f"{path} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(str(path))
+    lib.umx_model_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.c_char_p]
+    lib.umx_model_free.argtypes = [C.c_void_p]
+    lib.umx_model_hidden.argtypes = [C.c_void_p]
+    lib.umx_model_n_tensors.argtypes = [C.c_void_p]
+    lib.umx_model_views.restype = C.POINTER(TensorView)
+    lib.umx_model_views.argtypes = [C.c_void_p]
+    lib.umx_model_data_bytes.restype = C.c_size_t
+    lib.umx_model_data_bytes.argtypes = [C.c_void_p]
+    lib.umx_model_load_progress.restype = C.c_float
+    lib.umx_model_load_progress.argtypes = [C.c_void_p]
+    lib.umx_model_dequantize.restype = C.c_long
+    lib.umx_model_dequantize.argtypes = [C.c_void_p, C.c_int, C.c_char_p, _fp, C.c_size_t]
+    lib.umx_wav_load.argtypes = [C.c_char_p, C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p]
+    lib.umx_wav_free.argtypes = [_fp]
+    lib.umx_wav_write_f32.argtypes = [C.c_char_p, _fp, C.c_int, C.c_char_p]
+    lib.umx_split_inference.argtypes = [C.POINTER(Backend), _fp, C.c_int, C.c_int, C.POINTER(_fp), PROGRESS_FN,
+                                        C.c_void_p, C.c_char_p]
+    lib.umx_shift_inference.argtypes = [C.POINTER(Backend), _fp, C.c_int, C.c_int, C.c_int, C.POINTER(_fp),
+                                        PROGRESS_FN, C.c_void_p, C.c_char_p]
+    lib.umx_segment_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    lib.umx_transition_weight.restype = C.c_float
+    lib.umx_transition_weight.argtypes = [C.c_int, C.c_int, C.c_int]
+    _host = lib
+    return lib
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"umx_host error {code}: {msg}")
+        self.code = code
+
+
+class HostModel:
+    """load_umx_model (model.cpp:42-574) through the C++ host loader; tensors stay quantised."""
+
+    def __init__(self, path):
+        self.lib = host_lib()
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = self.lib.umx_model_load(str(path).encode(), C.byref(h), err)
+        if rc:
+            raise HostError(rc, err.value.decode())
+        self.h = h
+        self.hidden = self.lib.umx_model_hidden(h)
+        self.n_tensors = self.lib.umx_model_n_tensors(h)
+
+    def views(self):
+        return self.lib.umx_model_views(self.h), self.n_tensors
+
+    def dequantize(self, target, name):
+        n = self.lib.umx_model_dequantize(self.h, target, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        a = np.empty(n, np.float32)
+        self.lib.umx_model_dequantize(self.h, target, name.encode(), a.ctypes.data_as(_fp), n)
+        return a
+
+    def data_bytes(self):
+        return self.lib.umx_model_data_bytes(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.umx_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def engine_from_host_model(hm, segment_samples=SEGMENT_SAMPLES, device=0):
+    """The CLI's path: C++ loader views -> umx_hip_create (no Python copy of the weights)."""
+    eng = Engine.__new__(Engine)
+    eng.lib = hip_lib()
+    views, n = hm.views()
+    h = C.c_void_p()
+    rc = eng.lib.umx_hip_create(C.byref(h), device, hm.hidden, segment_samples, views, n)
+    if rc != UMX_OK:
+        raise UmxError(rc, eng.lib.umx_hip_last_error(None).decode())
+    eng.h, eng.hidden, eng.N, eng._keep = h, hm.hidden, segment_samples, None
+    eng.T = eng.lib.umx_hip_nb_frames(h)
+    return eng
+
+
+def wav_load(path):
+    """load_audio (dsp.cpp:18-77): -> ((2,n) float32, channels in file)."""
+    lib = host_lib()
+    p, n, ch = _fp(), C.c_int(), C.c_int()
+    err = C.create_string_buffer(256)
+    rc = lib.umx_wav_load(str(path).encode(), C.byref(p), C.byref(n), C.byref(ch), err)
+    if rc:
+        raise HostError(rc, err.value.decode())
+    a = np.ctypeslib.as_array(p, shape=(n.value, 2)).copy()
+    lib.umx_wav_free(p)
+    return np.ascontiguousarray(a.T), ch.value
+
+
+def wav_write(path, wave):
+    """write_audio_file (dsp.cpp:80-101): (2,n) -> stereo float32 WAV."""
+    a = np.ascontiguousarray(np.asarray(wave, np.float32).T)
+    err = C.create_string_buffer(256)
+    rc = host_lib().umx_wav_write_f32(str(path).encode(), a.ctypes.data_as(_fp), a.shape[0], err)
+    if rc:
+        raise HostError(rc, err.value.decode())
+
+
+def segment_plan(length, segment_samples=SEGMENT_SAMPLES):
+    lib = host_lib()
+    n = lib.umx_segment_plan(length, segment_samples, None, None, 0)
+    offs, lens = (C.c_int * n)(), (C.c_int * n)()
+    lib.umx_segment_plan(length, segment_samples, offs, lens, n)
+    return list(offs), list(lens)
+
+
+def make_backend(segment_fn, reset_fn=None):
+    """Wrap Python callables as a umx_backend: segment_fn((2,n) array) -> 4 x (2,n) arrays."""
+    def _seg(_user, audio, n, out):
+        try:
+            wave = np.ctypeslib.as_array(audio, shape=(n, 2)).T
+            res = segment_fn(np.ascontiguousarray(wave))
+            for t in range(4):
+                dst = np.ctypeslib.as_array(out[t], shape=(n, 2))
+                dst[:, :] = np.asarray(res[t], np.float32).T
+            return 0
+        except Exception as e:  # noqa: BLE001 - surfaced as a backend error code
+            print("segment backend raised:", repr(e))
+            return 13
+
+    def _reset(_user):
+        if reset_fn is not None:
+            reset_fn()
+        return 0
+    cb_seg, cb_reset = SEGMENT_FN(_seg), RESET_FN(_reset)
+    be = Backend(cb_seg, cb_reset, None)
+    be._keep = (cb_seg, cb_reset)
+    return be
+
+
+def _run_driver(kind, backend, wave, segment_samples, offset=None, progress=None):
+    lib = host_lib()
+    wave = np.asarray(wave, np.float32)
+    L = wave.shape[1]
+    a = np.ascontiguousarray(wave.T).ravel()
+    outs = [np.empty(2 * L, np.float32) for _ in range(4)]
+    arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs])
+    err = C.create_string_buffer(256)
+    pcb = PROGRESS_FN((lambda p, _u: progress(p)) if progress else (lambda p, _u: None))
+    if kind == "split":
+        rc = lib.umx_split_inference(C.byref(backend), a.ctypes.data_as(_fp), L, segment_samples, arr, pcb, None, err)
+    else:
+        rc = lib.umx_shift_inference(C.byref(backend), a.ctypes.data_as(_fp), L, segment_samples,
+                                     -1 if offset is None else offset, arr, pcb, None, err)
+    if rc:
+        raise HostError(rc, err.value.decode())
+    return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs]
+
+
+def split_inference(backend, wave, segment_samples=SEGMENT_SAMPLES, progress=None):
+    """umx.cpp:152-295 through the C++ host driver."""
+    return _run_driver("split", backend, wave, segment_samples, progress=progress)
+
+
+def shift_inference(backend, wave, segment_samples=SEGMENT_SAMPLES, offset=None, progress=None):
+    """umx.cpp:99-150 through the C++ host driver (offset None = the reference's rand()%22050)."""
+    return _run_driver("shift", backend, wave, segment_samples, offset=offset, progress=progress)
+
+
+def engine_backend(eng, flags=0):
+    return make_backend(lambda w: eng.infer_segment(w, flags), eng.stream_reset)

@@ -1,0 +1,149 @@
+// split.cpp -- segmented apply: split_inference / shift_inference (host side of umx_host.h).
+// Follows umx.cpp:99-295 over a pluggable per-segment backend (the HIP engine in the product,
+// the oracle in CPU tests).  One deliberate deviation, declared in the header: sum_weight is
+// zero-initialised over its whole length.
+#include "../../include/umx_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+void seterr(char *err, const std::string &m)
+{
+    if (err)
+        snprintf(err, UMX_ERRLEN, "%s", m.c_str());
+}
+const float kOverlap = 0.25f; // inference.hpp:15
+} // namespace
+
+extern "C" float umx_transition_weight(int k, int chunk_len, int segment_samples)
+{
+    // umx.cpp:197-206: weight[i] = weight[N-1-i] = i+1 for i < N/2, / max, ^1.0; used as
+    // weight(k % chunk_length) (umx.cpp:246)
+    const int N = segment_samples;
+    const int i = k % chunk_len;
+    const float raw = (float)((i < N / 2) ? i + 1 : N - i);
+    const float mx = (float)(N / 2);
+    return std::pow(raw / mx, 1.0f);
+}
+
+extern "C" int umx_segment_plan(int length, int segment_samples, int *offsets, int *lengths, int cap)
+{
+    const int stride = (int)((1 - kOverlap) * segment_samples); // umx.cpp:181
+    int n = 0;
+    if (stride <= 0)
+        return 0;
+    for (long long offset = 0; offset < length; offset += stride) // umx.cpp:214
+    {
+        if (n < cap)
+        {
+            if (offsets)
+                offsets[n] = (int)offset;
+            if (lengths)
+                lengths[n] = std::min(segment_samples, length - (int)offset); // umx.cpp:217
+        }
+        ++n;
+    }
+    return n;
+}
+
+extern "C" int umx_split_inference(const umx_backend *be, const float *audio, int length, int segment_samples,
+                                   float *const out[4], void (*progress)(float, void *), void *progress_user,
+                                   char *err)
+{
+    if (!be || !be->segment || !audio || !out || length < 1 || segment_samples < 2)
+    {
+        seterr(err, "umx_split_inference: bad argument");
+        return UMX_ERR_ARG;
+    }
+    const int N = segment_samples;
+    const int stride = (int)((1 - kOverlap) * N);
+    if (be->reset) // umx.cpp:167-171: the 4 lstm_data are created (zeroed) once per track
+        if (int rc = be->reset(be->user))
+        {
+            seterr(err, "backend reset failed");
+            return rc;
+        }
+    std::vector<float> sum_w((size_t)length, 0.0f);
+    for (int t = 0; t < 4; ++t)
+        std::fill(out[t], out[t] + (size_t)2 * length, 0.0f); // umx.cpp:186-195
+    const float total_reps = std::ceil((float)length / (float)stride); // umx.cpp:208
+    float done = 0.f;
+    std::vector<float> chunk[4];
+    for (long long off = 0; off < length; off += stride)
+    {
+        const int offset = (int)off;
+        const int chunk_len = std::min(N, length - offset);
+        float *co[4];
+        for (int t = 0; t < 4; ++t)
+        {
+            chunk[t].assign((size_t)2 * chunk_len, 0.0f);
+            co[t] = chunk[t].data();
+        }
+        if (int rc = be->segment(be->user, audio + (size_t)2 * offset, chunk_len, co)) // umx.cpp:226-227
+        {
+            seterr(err, "segment backend failed at offset " + std::to_string(offset));
+            return rc ? rc : UMX_HOST_ERR_BACKEND;
+        }
+        done += 1.0f / total_reps; // umx.cpp:229
+        if (progress)
+            progress(done, progress_user);
+        for (int k = 0; k < N && offset + k < length; ++k) // umx.cpp:234-260
+        {
+            const float w = umx_transition_weight(k, chunk_len, N);
+            for (int t = 0; t < 4; ++t)
+            {
+                out[t][2 * (size_t)(offset + k)] += w * chunk[t][2 * (size_t)k];
+                out[t][2 * (size_t)(offset + k) + 1] += w * chunk[t][2 * (size_t)k + 1];
+            }
+            sum_w[offset + k] += w;
+        }
+    }
+    for (int t = 0; t < 4; ++t) // umx.cpp:264-273
+        for (int k = 0; k < length; ++k)
+        {
+            out[t][2 * (size_t)k] /= sum_w[k];
+            out[t][2 * (size_t)k + 1] /= sum_w[k];
+        }
+    return UMX_OK;
+}
+
+extern "C" int umx_shift_inference(const umx_backend *be, const float *audio, int length, int segment_samples,
+                                   int offset, float *const out[4], void (*progress)(float, void *),
+                                   void *progress_user, char *err)
+{
+    if (!be || !audio || !out || length < 1)
+    {
+        seterr(err, "umx_shift_inference: bad argument");
+        return UMX_ERR_ARG;
+    }
+    const int max_shift = UMX_MAX_SHIFT_SAMPLES; // umx.cpp:112-113
+    if (offset < 0)
+        offset = rand() % max_shift; // umx.cpp:115 (never seeded in the reference)
+    if (offset >= max_shift)
+    {
+        seterr(err, "shift offset must be < 22050");
+        return UMX_ERR_ARG;
+    }
+    const int L2 = length + max_shift - offset; // umx.cpp:120-122
+    std::vector<float> shifted((size_t)2 * L2, 0.0f);
+    memcpy(shifted.data() + (size_t)2 * offset, audio, sizeof(float) * 2 * (size_t)length);
+    std::vector<float> full[4];
+    float *fo[4];
+    for (int t = 0; t < 4; ++t)
+    {
+        full[t].resize((size_t)2 * L2);
+        fo[t] = full[t].data();
+    }
+    if (int rc = umx_split_inference(be, shifted.data(), L2, segment_samples, fo, progress, progress_user, err))
+        return rc;
+    for (int t = 0; t < 4; ++t) // umx.cpp:136-147
+        memcpy(out[t], full[t].data() + (size_t)2 * offset, sizeof(float) * 2 * (size_t)length);
+    return UMX_OK;
+}
