@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--segment-samples", type=int, default=SEG)
     ap.add_argument("--no-wiener", action="store_true")
     ap.add_argument("--stepwise-lstm", action="store_true")
+    ap.add_argument("--safe-lstm", action="store_true", help="persistent LSTM kernel without the intra-XCD hand-off")
+    ap.add_argument("--lstm-profile", action="store_true", help="print per-phase shader-clock counters of the LSTM kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -112,7 +114,8 @@ def main():
     wave = pkg.ggml.synth_audio(N, seed=rank)  # each rank: its own track
     audio = torch.from_numpy(np.ascontiguousarray(wave.T).ravel()).to(dev)  # (2,n) interleaved, in HBM
     outs = [torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)]
-    flags = (pkg.FLAG_NO_WIENER if args.no_wiener else 0) | (pkg.FLAG_LSTM_STEPWISE if args.stepwise_lstm else 0)
+    flags = (pkg.FLAG_NO_WIENER if args.no_wiener else 0) | (pkg.FLAG_LSTM_STEPWISE if args.stepwise_lstm else 0) | \
+        (pkg.FLAG_LSTM_FORCE_SAFE if args.safe_lstm else 0) | (pkg.FLAG_LSTM_PROFILE if args.lstm_profile else 0)
     ptrs = [o.data_ptr() for o in outs]
 
     def step():
@@ -177,7 +180,8 @@ def main():
                                     " on 1 MI355X per rank; seeded synthetic 44.1 kHz stereo, synthetic "
                                     "UMX-L-shaped u8/u16 ggml weights"),
                        "hidden": H, "segment_samples": N, "frames": T, "stems": 4,
-                       "lstm": "persistent" if eng.lstm_was_persistent() else "stepwise",
+                       "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(
+                           eng.lstm_mode(), "?"),
                        "sharding": f"{world} independent segments (one per rank)"},
             "roofline": roofline,
             "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -191,6 +195,14 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(line), flush=True)
+        if args.lstm_profile:
+            pr = eng.lstm_profile()
+            for layer in range(3):
+                for w in range(2):
+                    c = pr[layer, w]
+                    n = max(int(c[4]), 1)
+                    print(f"# lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
+                          f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} (steps {int(c[4])})", file=sys.stderr)
     eng.close()
     if world > 1:
         dist.barrier()

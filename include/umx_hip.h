@@ -41,6 +41,8 @@ extern "C" {
 #define UMX_FLAG_SKIP_TARGET(t) (0x100 << (t)) /* BASELINE config 1 (vocals only = skip 0,1,2) */
 #define UMX_FLAG_LSTM_STEPWISE 0x10 /* one launch per timestep instead of the persistent kernel */
 #define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the mask tap (T x 4098 per target) for umx_hip_read_tap */
+#define UMX_FLAG_LSTM_FORCE_SAFE 0x40 /* persistent kernel: never take the intra-XCD fast protocol */
+#define UMX_FLAG_LSTM_PROFILE 0x80  /* persistent kernel: record per-phase cycle counters */
 
 /* One tensor of the ggml-style weight file, as stored (scripts/convert-umx-pth-to-ggml.py:146-160
  * record = {scale, offset, n_dims, name_len, ne[], name, data}).  dtype F32 means `data` is already
@@ -106,6 +108,12 @@ int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap
 /* 1 if the LSTM layers of the last segment ran in the persistent (one launch per layer) kernel,
  * 0 if the per-timestep driver was used (flag, unsupported hidden size, or grid not co-resident). */
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);
+/* 0 = per-timestep driver, 1 = persistent kernel with the placement-independent (sc1) hand-off,
+ * 2 = persistent kernel whose census found every chain on one XCD (intra-L2 hand-off); < 0 on error */
+int umx_hip_lstm_mode(umx_hip_ctx *ctx);
+/* UMX_FLAG_LSTM_PROFILE: shader-clock cycles summed over the T steps of each layer, for waves 0 and 1
+ * of workgroup (chain 0, slice 0): out48[(layer*2 + wave)*8 + {0 poll, 1 dot, 2 barrier, 3 gates, 4 steps}] */
+int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48);
 
 #ifdef __cplusplus
 }

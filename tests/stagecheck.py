@@ -54,6 +54,7 @@ def stage_report(hidden=128, n_buf=16 * 1024, n=None, flags=0, seed=5, segments=
             r[f"wave_maxabs[{t}]"] = float(np.abs(got[t] - ref[t]).max())
         r["state"] = rel(eng.stream_get(), state)
         r["persistent"] = eng.lstm_was_persistent()
+        r["lstm_mode"] = eng.lstm_mode()
         r["t_oracle_s"], r["t_hip_s"] = t_or, t_hip
         rep[seg] = r
         if verbose:

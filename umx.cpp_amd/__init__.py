@@ -25,6 +25,8 @@ DTYPE_F32, DTYPE_U8, DTYPE_U16 = 0, 1, 2
 FLAG_NO_WIENER = 0x1
 FLAG_LSTM_STEPWISE = 0x10
 FLAG_DEBUG_TAPS = 0x20
+FLAG_LSTM_FORCE_SAFE = 0x40
+FLAG_LSTM_PROFILE = 0x80
 
 
 def FLAG_SKIP_TARGET(t):
@@ -86,6 +88,8 @@ def hip_lib():
     lib.umx_hip_read_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _fp, C.c_size_t]
     lib.umx_hip_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), _fp, C.c_int]
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
+    lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
+    lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     _hip = lib
     return lib
 
@@ -94,7 +98,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_destroy", "umx_hip_last_error", "umx_h
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
-               "umx_hip_lstm_was_persistent"]
+               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile"]
 
 
 def views_from_file_tensors(targets, quantised=True):
@@ -196,6 +200,16 @@ class Engine:
 
     def lstm_was_persistent(self):
         return bool(self.lib.umx_hip_lstm_was_persistent(self.h))
+
+    def lstm_mode(self):
+        """0 stepwise, 1 persistent (placement-independent hand-off), 2 persistent (intra-XCD hand-off)."""
+        return self.lib.umx_hip_lstm_mode(self.h)
+
+    def lstm_profile(self):
+        buf = (C.c_ulonglong * 48)()
+        self._check(self.lib.umx_hip_debug_lstm_profile(self.h, buf))
+        a = np.array(buf[:], dtype=np.uint64).reshape(3, 2, 8)
+        return a
 
     def tap(self, what, target=0):
         n = self.lib.umx_hip_read_tap(self.h, what.encode(), target, None, 0)

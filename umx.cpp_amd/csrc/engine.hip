@@ -72,7 +72,9 @@ struct umx_hip_ctx
     float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr;
     unsigned *maxabs = nullptr, *status = nullptr;
     float *state = nullptr, *hbuf = nullptr;
-    unsigned long long *granules = nullptr;
+    unsigned *lsync = nullptr;            // census + arrivals + granules of the persistent LSTM kernel
+    unsigned long long *lprof = nullptr; // optional phase counters
+    size_t lsync_words = 0;
     hipEvent_t ev[ST_COUNT + 1] = {};
     bool have_times = false, persistent_ok = true, last_persistent = false;
     unsigned last_flags = 0;
@@ -288,7 +290,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                         for (int u = 0; u < 16; ++u)
                         {
                             const int row = g * Hl + sl * 16 + u; // PyTorch gate row (i|f|g|o blocks)
-                            const int col = g * 16 + u;
+                            const int col = u * 4 + g; // the 4 gates of a unit share a DPP quad
                             const size_t n = (size_t)dir * G + (size_t)sl * 64 + col;
                             memcpy(&ihw[n * H], &wih[(size_t)row * H], sizeof(float) * H);
                             ihb[n] = bih[row];
@@ -389,7 +391,10 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         return rc;
     if (int rc = dalloc(&hbuf, (size_t)2 * 8 * Hl))
         return rc;
-    if (int rc = dalloc(&granules, (size_t)2 * 8 * Hl))
+    lsync_words = LSTM_SYNC_HEADER_WORDS + (size_t)2 * 8 * Hl * 2;
+    if (int rc = dalloc(&lsync, lsync_words))
+        return rc;
+    if (int rc = dalloc(&lprof, 64))
         return rc;
     for (int i = 0; i <= ST_COUNT; ++i)
         UMX_HIP_CHECK(hipEventCreate(&ev[i]));
@@ -415,8 +420,10 @@ int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool ste
     a.bhh = bhh[layer];
     a.state = state;
     a.hbuf = hbuf;
-    a.granules = granules;
+    a.sync = lsync;
     a.status = status;
+    a.prof = (last_flags & UMX_FLAG_LSTM_PROFILE) ? lprof : nullptr;
+    a.force_safe = (last_flags & UMX_FLAG_LSTM_FORCE_SAFE) ? 1 : 0;
     a.Hl = Hl;
     a.S = S;
     a.T = T;
@@ -447,12 +454,13 @@ int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool ste
         a.tmap[i] = i < nact ? active[i] : 0;
     }
     const int nchains = 2 * nact;
+    a.nchains = nchains;
     const dim3 grid(S, nchains), block(LSTM_THREADS);
     const int kpw = Hl / 8;
     bool persistent = !stepwise && persistent_ok && (kpw == 8 || kpw == 16 || kpw == 32 || kpw == 64);
     if (persistent)
     {
-        UMX_HIP_CHECK(hipMemsetAsync(granules, 0, sizeof(unsigned long long) * 2 * 8 * Hl, stream));
+        UMX_HIP_CHECK(hipMemsetAsync(lsync, 0, sizeof(unsigned) * lsync_words, stream));
         void *kargs[] = {&a};
         const void *fn = kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8>)
                          : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16>)
@@ -460,7 +468,9 @@ int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool ste
                                      : reinterpret_cast<const void *>(lstm_persistent_kernel<64>);
         // cooperative launch = the runtime verifies that the whole grid is co-resident, which the
         // granule exchange needs; an over-size grid is refused instead of deadlocking
-        hipError_t e = hipLaunchCooperativeKernel(fn, grid, block, kargs, 0, stream);
+        // always 8*S workgroups: with round-robin dispatch every XCD then receives S of them and the
+        // census can enable the intra-XCD protocol; surplus workgroups (skipped targets) exit at once
+        hipError_t e = hipLaunchCooperativeKernel(fn, dim3(8 * S), block, kargs, 0, stream);
         if (e != hipSuccess)
         {
             (void)hipGetLastError();
@@ -841,5 +851,26 @@ int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap
 }
 
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx) { return ctx && ctx->last_persistent ? 1 : 0; }
+
+int umx_hip_lstm_mode(umx_hip_ctx *ctx)
+{
+    if (!ctx || !ctx->last_persistent)
+        return 0;
+    unsigned st[2] = {0, 0};
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(st, ctx->status, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return st[1] ? 2 : 1;
+}
+
+int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48)
+{
+    if (!ctx || !out48)
+        return UMX_ERR_ARG;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(out48, ctx->lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
+        return UMX_ERR_HIP;
+    return UMX_OK;
+}
 
 } // extern "C"

@@ -7,8 +7,9 @@
 // 4 targets x 2 directions = 8 independent chains per layer run concurrently.
 //
 // Work split: one workgroup (512 threads, 8 waves) per (chain, slice of 16 hidden units).
-// A slice owns the 64 gate columns {g*Hl + 16*slice + u}; lane l of every wave is gate column
-// l = g*16 + u; wave w owns the k-range [w*Hl/8, (w+1)*Hl/8) of the W_hh . h contraction.
+// A slice owns the 64 gate columns of its units; lane l of every wave is gate column
+// l = 4*u + g (unit u, gate g: the four gates of a unit sit in one DPP quad); wave w owns the
+// k-range [w*Hl/8, (w+1)*Hl/8) of the W_hh . h contraction.
 //   W    float [chains][S][Hl][64]     (k-major: a wave reads 64 consecutive floats per k)
 //   bhh  float [chains][S][64]
 //   P    float [Tp][2][S][64] per target (GEMM output, columns permuted to match)
@@ -16,22 +17,30 @@
 //
 // Two drivers share the same per-step arithmetic (bitwise-identical results):
 //   lstm_step_kernel        one launch per timestep, h/c in HBM between launches (simple, safe)
-//   lstm_persistent_kernel  one launch per layer: W_hh stays in VGPRs for all T steps, h is
-//                           exchanged between the chain's workgroups through 8-byte
-//                           {tag, value} granules written with agent-scope (sc1, write-through)
-//                           stores and polled with agent-scope relaxed loads -- the
-//                           placement-independent "data is the flag" hand-off.  Each wave
-//                           polls exactly the Hl/8 (<= 64) granules of its own k-range, one per
-//                           lane, and broadcasts them with v_readlane, so h never goes
-//                           through LDS.  Two granule slots (step parity) are enough: a
-//                           producer can only overwrite slot p two steps later, which needs
-//                           every consumer's next h, i.e. every consumer is past its reads.
+//   lstm_persistent_kernel  one launch per layer: W_hh stays in VGPRs for all T steps and h is
+//     exchanged between the chain's workgroups through 8-byte {tag = step, value} granules
+//     ("the data is the flag": one naturally aligned 8-byte store per value, polled with
+//     L1-bypassing loads, no fences).  Each wave polls exactly the Hl/8 (<= 64) granules of its
+//     own k-range, one per lane, and broadcasts them lane -> SGPR pair (v_readlane) into
+//     v_pk_fma_f32, so h never goes through LDS.  Two granule slots (step parity) are enough: a
+//     producer can only overwrite slot p two steps later, which needs every consumer's next h,
+//     i.e. every consumer is past its reads.
+//     Placement: measured on MI355X (tools/handoff_probe.hip) a write-through (sc1) store +
+//     sc1 load hand-off costs ~0.42-0.62 us one way and works for any placement; a plain store
+//     + sc1 load costs ~0.25 us but is only coherent inside one XCD (one L2).  The kernel
+//     therefore takes a CENSUS first: every workgroup registers on the XCD it actually runs on
+//     (HW_REG_XCC_ID), one grid barrier, and only if every XCD received exactly S workgroups
+//     does chain c become "the S workgroups on XCD c" with the fast intra-L2 protocol;
+//     otherwise roles are static and the protocol is the placement-independent sc1 one.
+//     Correctness never depends on where the dispatcher put a workgroup -- only speed does.
 // Floor for one segment: 3 layers x 2584 steps = 7752 serially dependent steps.
 #pragma once
 #include "common.h"
 
 namespace umx
 {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 struct LstmArgs
 {
@@ -41,21 +50,28 @@ struct LstmArgs
     float *out[4];    // out[target][t*ldo + col0 + dir*Hl + unit]
     float *state;     // [4 targets][3 layers][2 dirs][2 (h,c)][Hl]   (lstm.hpp:10-16 h, c)
     float *hbuf;      // step driver: [2][chains][Hl] ping-pong h
-    unsigned long long *granules; // persistent driver: [2][chains][Hl]
-    unsigned *status; // [0] = abort/timeout flag (0 = ok)
-    int Hl, S, T, ldp, ldo, col0, layer;
-    int tmap[4];      // grid chain>>1 -> target (targets can be skipped: BASELINE config 1)
+    unsigned *sync;   // persistent driver: [0..7] census per XCD, [8] arrivals, [16..] granules as u64 [2][8][Hl]
+    unsigned *status; // [0] = abort/timeout flag (0 = ok), [1] = 1 if the fast intra-XCD protocol ran
+    unsigned long long *prof; // optional phase-cycle counters (nullptr = off)
+    int Hl, S, T, ldp, ldo, col0, layer, nchains;
+    int tmap[4];      // chain>>1 -> target (targets can be skipped: BASELINE config 1)
+    int force_safe;   // 1 = never use the intra-XCD protocol (testing)
 };
+
+constexpr int LSTM_SYNC_HEADER_WORDS = 16; // census[8], arrivals, pad -> granules start 64-byte aligned
 
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); } // lstm.cpp:36-39
 
-// pre-activation (all 64 lanes of wave 0) -> new (c, h) on lanes 0..15
+// pre-activation of gate column lane = 4*u + g (all 64 lanes) -> new (c, h), replicated in the quad
 __device__ __forceinline__ void lstm_cell(float pre, int lane, float &c, float &h)
 {
-    const int g = lane >> 4, u = lane & 15;
+    const int g = lane & 3;
     const float act = (g == 2) ? tanhf(pre) : sigmoid_ref(pre);
-    const float i_t = __shfl(act, u), f_t = __shfl(act, 16 + u), g_t = __shfl(act, 32 + u),
-                o_t = __shfl(act, 48 + u);
+    const int ai = __float_as_int(act);
+    const float i_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, true)); // quad_perm [0,0,0,0]
+    const float f_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, true)); // [1,1,1,1]
+    const float g_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, true)); // [2,2,2,2]
+    const float o_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, true)); // [3,3,3,3]
     const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
     c = c_t;
     h = o_t * tanhf(c_t); // lstm.cpp:157
@@ -83,10 +99,17 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmArgs a, int
     __syncthreads();
     const int kpw = Hl >> 3;
     const float *Wp = a.W + (((size_t)wchain * a.S + slice) * Hl + (size_t)w * kpw) * 64 + l;
-    float acc = 0.f;
-    for (int i = 0; i < kpw; ++i)
-        acc = fmaf(Wp[(size_t)i * 64], hs[w * kpw + i], acc);
-    part[w][l] = acc;
+    float2v acc = {0.f, 0.f}; // even-k / odd-k partial sums, same order as the persistent kernel
+    for (int i = 0; i < kpw; i += 2)
+    {
+        float2v wv, hv;
+        wv.x = Wp[(size_t)i * 64];
+        wv.y = Wp[(size_t)(i + 1) * 64];
+        hv.x = hs[w * kpw + i];
+        hv.y = hs[w * kpw + i + 1];
+        acc = __builtin_elementwise_fma(wv, hv, acc);
+    }
+    part[w][l] = acc.x + acc.y;
     __syncthreads();
     if (w == 0)
     {
@@ -96,11 +119,11 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmArgs a, int
             s += part[ww][l];
         const float p = a.P[target][(size_t)t * a.ldp + ((size_t)dir * a.S + slice) * 64 + l];
         const float pre = (p + s) + a.bhh[((size_t)wchain * a.S + slice) * 64 + l]; // lstm.cpp:132-140
-        const int unit = slice * 16 + (l & 15);
+        const int unit = slice * 16 + (l >> 2);
         float *cst = a.state + state_off(target, a.layer, dir, 1, Hl);
-        float c = (l < 16) ? cst[unit] : 0.f, h;
+        float c = cst[unit], h;
         lstm_cell(pre, l, c, h);
-        if (l < 16)
+        if ((l & 3) == 0)
         {
             cst[unit] = c;
             a.hbuf[((size_t)((step + 1) & 1) * nchains + chain) * Hl + unit] = h;
@@ -128,44 +151,67 @@ __global__ void lstm_hbuf_to_state(LstmArgs a, int nchains)
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spin: ~seconds, then abort the launch
+constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then abort the launch
 
-// KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64.
-template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persistent_kernel(LstmArgs a)
+__device__ __forceinline__ unsigned xcc_id()
 {
-    __shared__ float part[2][8][64];
-    __shared__ int abort_flag;
-    const int slice = blockIdx.x, chain = blockIdx.y, target = a.tmap[chain >> 1], dir = chain & 1;
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xF;
+}
+
+// 8-byte granule store / load.  FAST (all parties share one XCD L2): plain store, L1-bypassing load.
+// SAFE (any placement): write-through agent-scope store + agent-scope load.
+template <bool FAST> __device__ __forceinline__ void granule_store(gu64 *p, unsigned long long v)
+{
+    if (FAST)
+        asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ... sc1
+}
+__device__ __forceinline__ unsigned long long granule_load(gu64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_load_dwordx2 ... sc1
+}
+
+// KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64, even.
+template <int KPW, bool FAST>
+__device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chain, int slice, float (*part)[8][64],
+                                                      int *abort_flag)
+{
+    const int target = a.tmap[chain >> 1], dir = chain & 1;
     const int wchain = target * 2 + dir;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     constexpr int Hl = KPW * 8;
-    const int nchains = gridDim.y, T = a.T;
+    const int T = a.T;
 
-    // W_hh slice -> registers, once
-    float W[KPW];
+    // W_hh slice -> registers, once: pairs (k even, k odd) feed v_pk_fma_f32
+    float2v W[KPW / 2];
     {
         const float *Wp = a.W + (((size_t)wchain * a.S + slice) * Hl + (size_t)w * KPW) * 64 + l;
 #pragma unroll
-        for (int i = 0; i < KPW; ++i)
-            W[i] = Wp[(size_t)i * 64];
+        for (int i = 0; i < KPW / 2; ++i)
+        {
+            W[i].x = Wp[(size_t)(2 * i) * 64];
+            W[i].y = Wp[(size_t)(2 * i + 1) * 64];
+        }
     }
     const float bh = a.bhh[((size_t)wchain * a.S + slice) * 64 + l];
-    const int unit = slice * 16 + (l & 15);
+    const int unit = slice * 16 + (l >> 2);
     float c = 0.f;
-    if (w == 0 && l < 16)
+    if (w == 0)
         c = a.state[state_off(target, a.layer, dir, 1, Hl) + unit];
     // h_{-1}: this wave's k-range, one value per lane (lanes >= KPW idle)
     float hval = 0.f;
     if (l < KPW)
         hval = a.state[state_off(target, a.layer, dir, 0, Hl) + w * KPW + l];
-    if (tid == 0)
-        abort_flag = 0;
-    __syncthreads();
 
-    gu64 *gran = (gu64 *)a.granules;
+    gu64 *gran = (gu64 *)(a.sync + LSTM_SYNC_HEADER_WORDS);
     gu32 *status = (gu32 *)a.status;
     const float *Pp = a.P[target] + ((size_t)dir * a.S + slice) * 64 + l;
     float hlast = 0.f;
+    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && l == 0 && w < 2;
+    unsigned long long pc[5] = {0, 0, 0, 0, 0};
 
     for (int step = 0; step < T; ++step)
     {
@@ -173,10 +219,13 @@ template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persiste
         float p = 0.f;
         if (w == 0)
             p = Pp[(size_t)t * a.ldp]; // issued before the poll: latency hides behind it
+        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (prof)
+            c0 = clock64();
         if (step > 0)
         {
             // wait for h_{step-1}: tag == step, slot (step-1)&1
-            gu64 *g = gran + ((size_t)((step - 1) & 1) * nchains + chain) * Hl + w * KPW + l;
+            gu64 *g = gran + ((size_t)((step - 1) & 1) * 8 + chain) * Hl + w * KPW + l;
             const unsigned want = (unsigned)step;
             bool ok = (l >= KPW);
             unsigned long long x = 0;
@@ -185,7 +234,7 @@ template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persiste
             {
                 if (!ok)
                 {
-                    x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x = granule_load(g);
                     ok = (unsigned)(x >> 32) == want;
                 }
                 if (__all(ok))
@@ -195,50 +244,118 @@ template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persiste
                 {
                     if (l == 0)
                         __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    abort_flag = 1;
+                    *abort_flag = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                if (!FAST)
+                    __builtin_amdgcn_s_sleep(1);
             }
             hval = __uint_as_float((unsigned)x);
         }
-        // partial dot product over this wave's k-range, h broadcast lane -> SGPR
-        float acc = 0.f;
+        if (prof)
+            c1 = clock64();
+        // partial dot product over this wave's k-range, h broadcast lane -> SGPR pair
+        float2v acc = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < KPW; ++i)
+        for (int i = 0; i < KPW / 2; ++i)
         {
-            const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), i));
-            acc = fmaf(W[i], hk, acc);
+            float2v hk;
+            hk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i));
+            hk.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i + 1));
+            acc = __builtin_elementwise_fma(W[i], hk, acc);
         }
-        part[step & 1][w][l] = acc;
+        (*(part + (step & 1)))[w][l] = acc.x + acc.y;
+        if (prof)
+            c2 = clock64();
         __syncthreads();
-        if (abort_flag) // uniform after the barrier: every wave leaves, nobody is left spinning on us
+        if (*abort_flag) // uniform after the barrier: every wave leaves, nobody is left spinning on us
             return;
+        if (prof)
+            c3 = clock64();
         if (w == 0)
         {
-            float s = part[step & 1][0][l];
+            float s = (*(part + (step & 1)))[0][l];
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww)
-                s += part[step & 1][ww][l];
+                s += (*(part + (step & 1)))[ww][l];
             const float pre = (p + s) + bh;
             float h;
             lstm_cell(pre, l, c, h);
-            if (l < 16)
+            if ((l & 3) == 0)
             {
                 const unsigned long long gv =
                     ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(h);
-                __hip_atomic_store(gran + ((size_t)(step & 1) * nchains + chain) * Hl + unit, gv,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                granule_store<FAST>(gran + ((size_t)(step & 1) * 8 + chain) * Hl + unit, gv);
                 a.out[target][(size_t)t * a.ldo + a.col0 + dir * Hl + unit] = h;
                 hlast = h;
             }
         }
+        if (prof)
+        {
+            const long long c4 = clock64();
+            pc[0] += (unsigned long long)(c1 - c0); // poll
+            pc[1] += (unsigned long long)(c2 - c1); // dot
+            pc[2] += (unsigned long long)(c3 - c2); // barrier
+            pc[3] += (unsigned long long)(c4 - c3); // gates + publish (wave 0) / nothing (wave 1)
+            pc[4] += 1;
+        }
     }
-    if (w == 0 && l < 16) // lstm.cpp:160-161: the state carries into the next segment
+    if (w == 0 && (l & 3) == 0) // lstm.cpp:160-161: the state carries into the next segment
     {
         a.state[state_off(target, a.layer, dir, 0, Hl) + unit] = hlast;
         a.state[state_off(target, a.layer, dir, 1, Hl) + unit] = c;
     }
+    if (prof)
+        for (int i = 0; i < 5; ++i)
+            a.prof[(a.layer * 2 + w) * 8 + i] = pc[i];
+}
+
+// grid = 8*S workgroups (1-D), cooperative launch.  Roles come from the census (see file header).
+template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persistent_kernel(LstmArgs a)
+{
+    __shared__ float part[2][8][64];
+    __shared__ int s_ctl[4]; // chain, slice, fast, abort
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x, S = a.S;
+    if (tid == 0)
+    {
+        gu32 *census = (gu32 *)a.sync;
+        gu32 *arrived = (gu32 *)(a.sync + 8);
+        gu32 *status = (gu32 *)a.status;
+        const unsigned xcc = xcc_id() & 7;
+        const unsigned ticket = __hip_atomic_fetch_add(census + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int abort_ = 0;
+        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg)
+        {
+            if (++spins > LSTM_SPIN_LIMIT)
+            {
+                __hip_atomic_store(status, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                abort_ = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        bool fast = !a.force_safe && !abort_;
+        for (int x = 0; x < 8; ++x)
+            fast = fast && __hip_atomic_load(census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)S;
+        s_ctl[0] = fast ? (int)xcc : (int)(blockIdx.x / S);
+        s_ctl[1] = fast ? (int)ticket : (int)(blockIdx.x % S);
+        s_ctl[2] = fast;
+        s_ctl[3] = abort_;
+        if (blockIdx.x == 0)
+            __hip_atomic_store(status + 1, fast ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int chain = s_ctl[0], slice = s_ctl[1];
+    if (s_ctl[3] || chain >= a.nchains) // aborted, or an XCD / block range with no chain to run
+        return;
+    if (s_ctl[2])
+        lstm_persistent_body<KPW, true>(a, chain, slice, part, &s_ctl[3]);
+    else
+        lstm_persistent_body<KPW, false>(a, chain, slice, part, &s_ctl[3]);
 }
 
 } // namespace umx
