@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--lstm-profile", action="store_true", help="print per-phase shader-clock counters of the LSTM kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
+    ap.add_argument("--serial", action="store_true", help="sync after every segment (no cross-segment pipelining)")
     args = ap.parse_args()
 
     import torch
@@ -120,6 +121,8 @@ def main():
 
     def step():
         eng.infer_segment_device(audio.data_ptr(), N, ptrs, flags)
+        if args.serial:
+            eng.sync()
 
     def fence():
         eng.sync()
@@ -141,8 +144,18 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    # per-stage device time of the last segment, from hipEvents on the engine's own stream
-    stage_ms = eng.stage_times()
+    # per-stage device time, from hipEvents on the engine's own streams: taken from extra segments run one
+    # at a time AFTER the timed region (in the timed region consecutive segments overlap, so a stage's
+    # event span there includes the other slot's kernels)
+    pipelined_ms = dt / args.steps * 1e3
+    serial = []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        step()
+        eng.sync()
+        serial.append((time.perf_counter() - t1) * 1e3)
+        stage_ms = eng.stage_times()
+    serial_ms = min(serial)
     finite = bool(all(torch.isfinite(o).all().item() for o in outs))
 
     if rank == 0:
@@ -185,6 +198,7 @@ def main():
                        "sharding": f"{world} independent segments (one per rank)"},
             "roofline": roofline,
             "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "ms_per_segment_unpipelined": round(serial_ms, 3),
             "gemm_tflops": round(gemm_tf, 2) if gemm_tf else None,
             "streaming_gbs": round(stream_gbs, 1) if stream_gbs else None,
             "outputs_finite": finite,

@@ -43,6 +43,8 @@ extern "C" {
 #define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the mask tap (T x 4098 per target) for umx_hip_read_tap */
 #define UMX_FLAG_LSTM_FORCE_SAFE 0x40 /* persistent kernel: never take the intra-XCD fast protocol */
 #define UMX_FLAG_LSTM_PROFILE 0x80  /* persistent kernel: record per-phase cycle counters */
+#define UMX_FLAG_PRECISE_ACT 0x1000 /* LSTM gates with the device-library expf/tanhf + IEEE division instead of
+                                       the hardware v_exp_f32 / v_rcp_f32 forms (~1e-7 abs difference) */
 
 /* One tensor of the ggml-style weight file, as stored (scripts/convert-umx-pth-to-ggml.py:146-160
  * record = {scale, offset, n_dims, name_len, ne[], name, data}).  dtype F32 means `data` is already

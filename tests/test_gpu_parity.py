@@ -28,7 +28,7 @@ TOL_STAGE, TOL_Y, TOL_WAVE, MIN_SDR = 2e-5, 2e-4, 1e-4, 80.0
 def _check_report(rep):
     for seg, r in rep.items():
         for k, v in r.items():
-            if k.startswith(("spec", "mix_mag", "x", "fc1", "lstm", "mask", "target_mag", "state")):
+            if k.startswith(("spec", "mix_mag", "x", "fc1", "lstm[", "mask", "target_mag", "state")):
                 assert v < TOL_STAGE, (seg, k, v)
             elif k.startswith("y["):
                 assert v < TOL_Y, (seg, k, v)
@@ -71,12 +71,41 @@ def test_persistent_and_stepwise_lstm_are_bitwise_identical(pkg, small):
     a = eng.infer_segment(wave)
     sa = eng.stream_get()
     assert eng.lstm_was_persistent()
-    eng.stream_reset()
-    b = eng.infer_segment(wave, pkg.FLAG_LSTM_STEPWISE)
-    sb = eng.stream_get()
-    assert not eng.lstm_was_persistent()
-    assert (sa == sb).all()
-    assert all((a[t] == b[t]).all() for t in range(4))
+    assert eng.lstm_mode() == 2  # census found every chain on one XCD
+    for flag, mode in ((pkg.FLAG_LSTM_STEPWISE, 0), (pkg.FLAG_LSTM_FORCE_SAFE, 1)):
+        eng.stream_reset()
+        b = eng.infer_segment(wave, flag)
+        sb = eng.stream_get()
+        assert eng.lstm_mode() == mode
+        assert (sa == sb).all()
+        assert all((a[t] == b[t]).all() for t in range(4))
+
+
+def test_umxl_persistent_modes_and_stepwise_are_bitwise_identical(pkg, tmp_path):
+    """hidden=1024: the DPP-rotation kernel (intra-XCD and sc1 hand-off) and the per-step driver walk k
+    in the same order, so all three give the same bits; so do the precise-activation variants."""
+    H, N = 1024, 48 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=23), H, compress=False)
+    eng = pkg.Engine.from_file(path, N)
+    wave = pkg.ggml.synth_audio(N, 77)
+    res = {}
+    for name, flags in (("fast", 0), ("safe", pkg.FLAG_LSTM_FORCE_SAFE), ("step", pkg.FLAG_LSTM_STEPWISE)):
+        for prec in (0, pkg.FLAG_PRECISE_ACT):
+            eng.stream_reset()
+            out = eng.infer_segment(wave, flags | prec)
+            res[(name, prec)] = (out, eng.stream_get(), eng.lstm_mode())
+    assert res[("fast", 0)][2] == 2 and res[("safe", 0)][2] == 1 and res[("step", 0)][2] == 0
+    for prec in (0, pkg.FLAG_PRECISE_ACT):
+        ref_out, ref_state, _ = res[("fast", prec)]
+        for name in ("safe", "step"):
+            out, state, _ = res[(name, prec)]
+            assert (state == ref_state).all(), (name, prec)
+            assert all((out[t] == ref_out[t]).all() for t in range(4)), (name, prec)
+    # the two activation flavours differ only at the 1e-7 level
+    a, b = res[("fast", 0)][0], res[("fast", pkg.FLAG_PRECISE_ACT)][0]
+    assert 0 < max(np.abs(a[t] - b[t]).max() for t in range(4)) < 1e-5
+    eng.close()
 
 
 def test_short_chunk_ragged_last_segment(pkg, po, small):

@@ -27,6 +27,7 @@ FLAG_LSTM_STEPWISE = 0x10
 FLAG_DEBUG_TAPS = 0x20
 FLAG_LSTM_FORCE_SAFE = 0x40
 FLAG_LSTM_PROFILE = 0x80
+FLAG_PRECISE_ACT = 0x1000
 
 
 def FLAG_SKIP_TARGET(t):
@@ -62,7 +63,7 @@ def hip_lib():
     global _hip
     if _hip is not None:
         return _hip
-    path = HERE / "libumx_hip.so"
+    path = Path(os.environ.get("UMX_HIP_LIB", HERE / "libumx_hip.so"))  # override = kernel-variant A/B runs
     if not path.exists():
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")

@@ -22,6 +22,7 @@ constexpr float WIENER_SCALE = 10.0f; // wiener.hpp:13
 
 constexpr int LSTM_UNITS_PER_WG = 16; // hidden units (x4 gates = 64 gate columns) per workgroup
 constexpr int LSTM_THREADS = 512;     // 8 waves: wave w owns k-range [w*Hl/8, (w+1)*Hl/8)
+constexpr int LSTM_PERSISTENT_THREADS = 576; // + 1 gate wave in the persistent kernel
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 

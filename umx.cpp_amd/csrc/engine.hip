@@ -2,11 +2,13 @@
 // Orchestrates one segment exactly like umx_inference (inference.cpp:12-207):
 //   stft -> |.| / crop+stack -> 4 x [fc1 bn tanh -> 3-layer BiLSTM -> fc2 bn relu -> fc3 bn scale
 //   relu -> mask*mix] -> Wiener EM -> 4 x istft
-// All kernels are queued on one HIP stream; the four targets run inside the same launches.
+// The four targets run inside the same launches; consecutive segments alternate between two pipeline
+// slots (streams) so that their LSTM layers overlap as an exact wavefront (see struct Slot).
 #include "../../include/umx_hip.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -24,14 +26,16 @@ namespace
 {
 std::string g_create_error = "";
 
-struct TargetBufs
+struct TargetBufs // weights of one target (shared by both pipeline slots)
 {
-    // weights
     float *fc1_w = nullptr, *in_scale = nullptr, *in_mean = nullptr, *bn1[4] = {};
     float *ih_w[3] = {}, *ih_b[3] = {};
     float *fc2_w = nullptr, *bn2[4] = {};
     float *fc3_w = nullptr, *bn3[4] = {}, *out_scale = nullptr, *out_mean = nullptr;
-    // activations
+};
+
+struct TargetAct // activations of one target in one pipeline slot
+{
     float *cat = nullptr, *la = nullptr, *lb = nullptr, *P = nullptr, *a2 = nullptr, *mag = nullptr,
           *mask_dbg = nullptr;
 };
@@ -55,12 +59,28 @@ enum
 };
 const char *kStageNames[ST_COUNT] = {"stft",  "fc1", "lstm_ih0", "lstm_rec0", "lstm_ih1", "lstm_rec1", "lstm_ih2",
                                      "lstm_rec2", "fc2", "fc3_mask", "wiener",  "istft",    "ola"};
+
+// One pipeline slot = everything one in-flight segment needs.  Two slots on two streams let segment
+// s+1 run its STFT/GEMMs and LSTM layer l while segment s is in layer l+1 (the exact wavefront of
+// R_l(s+1) waits only for R_l(s) through an event); the LSTM kernels are latency-bound
+// and use half of each CU's wave slots, so two of them co-reside and fill each other's hand-off gaps.
+struct Slot
+{
+    hipStream_t stream = nullptr;
+    TargetAct ta[4];
+    float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
+    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr, *hbuf = nullptr;
+    unsigned *maxabs = nullptr, *status = nullptr, *lsync = nullptr;
+    unsigned long long *lprof = nullptr;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    hipEvent_t rec_done[3] = {}; // LSTM layer l of this slot's segment has finished (state updated)
+    bool have_times = false, last_persistent = false, used = false;
+};
 } // namespace
 
 struct umx_hip_ctx
 {
     int device = 0, H = 0, Hl = 0, S = 0, N = 0, T = 0, Tp = 0, nbatch = 0;
-    hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> allocs;
     TargetBufs tb[4];
@@ -68,16 +88,16 @@ struct umx_hip_ctx
     float *window = nullptr, *nw = nullptr;
     float2 *tw1 = nullptr, *tw2 = nullptr;
     float *audio_in = nullptr, *out_dev[4] = {};
-    float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
-    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr;
-    unsigned *maxabs = nullptr, *status = nullptr;
-    float *state = nullptr, *hbuf = nullptr;
-    unsigned *lsync = nullptr;            // census + arrivals + granules of the persistent LSTM kernel
-    unsigned long long *lprof = nullptr; // optional phase counters
+    float *state = nullptr;
+    Slot slot[2];
+    int cur = 0;              // slot of the most recently queued segment
+    long long nseg = 0;       // segments queued since creation
     size_t lsync_words = 0;
-    hipEvent_t ev[ST_COUNT + 1] = {};
-    bool have_times = false, persistent_ok = true, last_persistent = false;
+    bool persistent_ok = true;
+    int lstm_threads = LSTM_THREADS; // 512 (two workgroups per CU fit) or 576 (dedicated gate wave)
+    int lstm_capacity = 0;           // workgroups of the persistent LSTM kernel that can be co-resident
     unsigned last_flags = 0;
+    hipStream_t stream = nullptr; // = slot[0].stream (H2D/D2H of the host-pointer entry point)
 
     void set_error(const std::string &s) { err = s; }
 
@@ -101,7 +121,8 @@ struct umx_hip_ctx
     }
     int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors);
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
-    int run_lstm_layer(int layer, const int *active, int nact, bool stepwise);
+    int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise);
+    int sync_all();
 };
 
 // ---------------------------------------------------------------- weights
@@ -161,7 +182,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     }
     device = device_;
     UMX_HIP_CHECK(hipSetDevice(device));
-    UMX_HIP_CHECK(hipStreamCreate(&stream));
     H = hidden;
     Hl = H / 2;
     S = Hl / LSTM_UNITS_PER_WG;
@@ -304,19 +324,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload(&b.ih_b[l], ihb))
                 return rc;
         }
-        // activations
-        if (int rc = dalloc(&b.cat, (size_t)Tp * 2 * H))
-            return rc;
-        if (int rc = dalloc(&b.la, (size_t)Tp * H))
-            return rc;
-        if (int rc = dalloc(&b.lb, (size_t)Tp * H))
-            return rc;
-        if (int rc = dalloc(&b.P, (size_t)Tp * 4 * H))
-            return rc;
-        if (int rc = dalloc(&b.a2, (size_t)Tp * H))
-            return rc;
-        if (int rc = dalloc(&b.mag, (size_t)2 * T * NBINS))
-            return rc;
     }
     for (int l = 0; l < 3; ++l)
     {
@@ -363,41 +370,83 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         if (int rc = upload(&tw2, t2))
             return rc;
     }
-    // ---- segment buffers
+    // ---- per-segment buffers: two pipeline slots
     if (int rc = dalloc(&audio_in, (size_t)2 * N))
         return rc;
-    for (int s = 0; s < 4; ++s)
-        if (int rc = dalloc(&out_dev[s], (size_t)2 * N))
+    for (int k = 0; k < 4; ++k)
+        if (int rc = dalloc(&out_dev[k], (size_t)2 * N))
             return rc;
-    if (int rc = dalloc(&spec, (size_t)2 * T * NBINS))
-        return rc;
-    if (int rc = dalloc(&mix_mag, (size_t)2 * T * NBINS))
-        return rc;
-    if (int rc = dalloc(&x, (size_t)Tp * KX))
-        return rc;
-    if (int rc = dalloc(&y, (size_t)4 * 2 * T * NBINS))
-        return rc;
-    if (int rc = dalloc(&frames, (size_t)4 * T * NFFT))
-        return rc;
-    if (int rc = dalloc(&wpart, (size_t)4 * nbatch * NBINS * 9))
-        return rc;
-    if (int rc = dalloc(&R, (size_t)4 * NBINS * 8))
-        return rc;
-    if (int rc = dalloc(&maxabs, 4))
-        return rc;
-    if (int rc = dalloc(&status, 4))
-        return rc;
     if (int rc = dalloc(&state, (size_t)4 * 12 * Hl))
         return rc;
-    if (int rc = dalloc(&hbuf, (size_t)2 * 8 * Hl))
-        return rc;
-    lsync_words = LSTM_SYNC_HEADER_WORDS + (size_t)2 * 8 * Hl * 2;
-    if (int rc = dalloc(&lsync, lsync_words))
-        return rc;
-    if (int rc = dalloc(&lprof, 64))
-        return rc;
-    for (int i = 0; i <= ST_COUNT; ++i)
-        UMX_HIP_CHECK(hipEventCreate(&ev[i]));
+    lsync_words = LSTM_SYNC_HEADER_WORDS + granule_count(S) * 2;
+    if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
+        lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
+    for (int si = 0; si < 2; ++si)
+    {
+        Slot &sl = slot[si];
+        UMX_HIP_CHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        for (int tg = 0; tg < 4; ++tg)
+        {
+            TargetAct &b = sl.ta[tg];
+            if (int rc = dalloc(&b.cat, (size_t)Tp * 2 * H))
+                return rc;
+            if (int rc = dalloc(&b.la, (size_t)Tp * H))
+                return rc;
+            if (int rc = dalloc(&b.lb, (size_t)Tp * H))
+                return rc;
+            if (int rc = dalloc(&b.P, (size_t)Tp * 4 * H))
+                return rc;
+            if (int rc = dalloc(&b.a2, (size_t)Tp * H))
+                return rc;
+            if (int rc = dalloc(&b.mag, (size_t)2 * T * NBINS))
+                return rc;
+        }
+        if (int rc = dalloc(&sl.spec, (size_t)2 * T * NBINS))
+            return rc;
+        if (int rc = dalloc(&sl.mix_mag, (size_t)2 * T * NBINS))
+            return rc;
+        if (int rc = dalloc(&sl.x, (size_t)Tp * KX))
+            return rc;
+        if (int rc = dalloc(&sl.y, (size_t)4 * 2 * T * NBINS))
+            return rc;
+        if (int rc = dalloc(&sl.frames, (size_t)4 * T * NFFT))
+            return rc;
+        if (int rc = dalloc(&sl.wpart, (size_t)4 * nbatch * NBINS * 9))
+            return rc;
+        if (int rc = dalloc(&sl.R, (size_t)4 * NBINS * 8))
+            return rc;
+        if (int rc = dalloc(&sl.maxabs, 4))
+            return rc;
+        if (int rc = dalloc(&sl.status, 4))
+            return rc;
+        if (int rc = dalloc(&sl.hbuf, (size_t)2 * 8 * Hl))
+            return rc;
+        if (int rc = dalloc(&sl.lsync, lsync_words))
+            return rc;
+        if (int rc = dalloc(&sl.lprof, 64))
+            return rc;
+        for (int i = 0; i <= ST_COUNT; ++i)
+            UMX_HIP_CHECK(hipEventCreate(&sl.ev[i]));
+        for (int l = 0; l < 3; ++l)
+            UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.rec_done[l], hipEventDisableTiming));
+    }
+    stream = slot[0].stream;
+    {
+        // residency of the persistent LSTM kernel (all instantiations have the same footprint class;
+        // take the one this hidden size uses)
+        const int kpw = Hl / 8;
+        const void *fn = kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, false>)
+                         : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, false>)
+                         : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, false>)
+                                     : reinterpret_cast<const void *>(lstm_persistent_kernel<64, false>);
+        int per_cu = 0, cus = 0;
+        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, lstm_threads, 0));
+        UMX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        lstm_capacity = per_cu * cus;
+        if (const char *e = getenv("UMX_LSTM_NO_OVERLAP")) // testing: never run two LSTM grids at once
+            if (atoi(e))
+                lstm_capacity = std::min(lstm_capacity, 2 * 8 * S - 1);
+    }
     // dynamic LDS > 64 KiB must be opted into
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -411,18 +460,26 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     return UMX_OK;
 }
 
-// ---------------------------------------------------------------- LSTM layer
-int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool stepwise)
+int umx_hip_ctx::sync_all()
 {
+    for (int si = 0; si < 2; ++si)
+        UMX_HIP_CHECK(hipStreamSynchronize(slot[si].stream));
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- LSTM layer
+int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise)
+{
+    hipStream_t st = sl.stream;
     LstmArgs a;
     memset(&a, 0, sizeof a);
     a.W = whh[layer];
     a.bhh = bhh[layer];
     a.state = state;
-    a.hbuf = hbuf;
-    a.sync = lsync;
-    a.status = status;
-    a.prof = (last_flags & UMX_FLAG_LSTM_PROFILE) ? lprof : nullptr;
+    a.hbuf = sl.hbuf;
+    a.sync = sl.lsync;
+    a.status = sl.status;
+    a.prof = (last_flags & UMX_FLAG_LSTM_PROFILE) ? sl.lprof : nullptr;
     a.force_safe = (last_flags & UMX_FLAG_LSTM_FORCE_SAFE) ? 1 : 0;
     a.Hl = Hl;
     a.S = S;
@@ -431,7 +488,7 @@ int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool ste
     a.layer = layer;
     for (int i = 0; i < 4; ++i)
     {
-        const TargetBufs &b = tb[i];
+        const TargetAct &b = sl.ta[i];
         a.P[i] = b.P;
         if (layer == 0)
         {
@@ -457,35 +514,49 @@ int umx_hip_ctx::run_lstm_layer(int layer, const int *active, int nact, bool ste
     a.nchains = nchains;
     const dim3 grid(S, nchains), block(LSTM_THREADS);
     const int kpw = Hl / 8;
-    bool persistent = !stepwise && persistent_ok && (kpw == 8 || kpw == 16 || kpw == 32 || kpw == 64);
+    bool persistent = !stepwise && persistent_ok && (kpw == 8 || kpw == 16 || kpw == 32 || kpw == 64) &&
+                      8 * S <= lstm_capacity;
     if (persistent)
     {
-        UMX_HIP_CHECK(hipMemsetAsync(lsync, 0, sizeof(unsigned) * lsync_words, stream));
+        UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * lsync_words, st));
         void *kargs[] = {&a};
-        const void *fn = kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8>)
-                         : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16>)
-                         : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32>)
-                                     : reinterpret_cast<const void *>(lstm_persistent_kernel<64>);
-        // cooperative launch = the runtime verifies that the whole grid is co-resident, which the
-        // granule exchange needs; an over-size grid is refused instead of deadlocking
+        const bool precise = last_flags & UMX_FLAG_PRECISE_ACT;
+        const void *fn =
+            precise ? (kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, true>)
+                       : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, true>)
+                       : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, true>)
+                                   : reinterpret_cast<const void *>(lstm_persistent_kernel<64, true>))
+                    : (kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, false>)
+                       : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, false>)
+                       : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, false>)
+                                   : reinterpret_cast<const void *>(lstm_persistent_kernel<64, false>));
+        // The granule exchange needs the whole grid co-resident.  Residency was checked against the
+        // occupancy of this kernel at create time (lstm_capacity); a plain launch is used because ROCm
+        // serialises cooperative launches against other queues, which would defeat the two-slot overlap.
+        // Every spin in the kernel is bounded, so a grid that is not resident after all ends as
+        // UMX_ERR_TIMEOUT, not as a hang.
         // always 8*S workgroups: with round-robin dispatch every XCD then receives S of them and the
         // census can enable the intra-XCD protocol; surplus workgroups (skipped targets) exit at once
-        hipError_t e = hipLaunchCooperativeKernel(fn, dim3(8 * S), block, kargs, 0, stream);
+        hipError_t e = hipLaunchKernel(fn, dim3(8 * S), dim3(lstm_threads), kargs, 0, st);
         if (e != hipSuccess)
         {
             (void)hipGetLastError();
-            persistent_ok = false; // e.g. fewer CUs than workgroups: use the per-step driver
+            persistent_ok = false;
             persistent = false;
         }
     }
     if (!persistent)
     {
-        hipLaunchKernelGGL(lstm_state_to_hbuf, dim3(nchains), dim3(256), 0, stream, a, nchains);
-        for (int step = 0; step < T; ++step)
-            hipLaunchKernelGGL(lstm_step_kernel, grid, block, 0, stream, a, step);
-        hipLaunchKernelGGL(lstm_hbuf_to_state, dim3(nchains), dim3(256), 0, stream, a, nchains);
+        hipLaunchKernelGGL(lstm_state_to_hbuf, dim3(nchains), dim3(256), 0, st, a, nchains);
+        if (last_flags & UMX_FLAG_PRECISE_ACT)
+            for (int step = 0; step < T; ++step)
+                hipLaunchKernelGGL(lstm_step_kernel<true>, grid, block, 0, st, a, step);
+        else
+            for (int step = 0; step < T; ++step)
+                hipLaunchKernelGGL(lstm_step_kernel<false>, grid, block, 0, st, a, step);
+        hipLaunchKernelGGL(lstm_hbuf_to_state, dim3(nchains), dim3(256), 0, st, a, nchains);
     }
-    last_persistent = persistent;
+    sl.last_persistent = persistent;
     UMX_HIP_CHECK(hipGetLastError());
     return UMX_OK;
 }
@@ -505,6 +576,13 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
             return UMX_ERR_ARG;
         }
     UMX_HIP_CHECK(hipSetDevice(device));
+    // pipeline slot: consecutive segments alternate slots/streams; a slot is reused two segments later
+    // (stream order protects its buffers).  Everything that touches the streaming LSTM state is ordered
+    // by events: R_l of this segment waits for R_l of the previous one.
+    const int si = (int)(nseg & 1);
+    Slot &sl = slot[si];
+    Slot &prev = slot[si ^ 1];
+    hipStream_t st = sl.stream;
     int active[4], nact = 0;
     for (int tg = 0; tg < 4; ++tg)
         if (!(flags & UMX_FLAG_SKIP_TARGET(tg)))
@@ -512,16 +590,16 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
     if (dbg)
         for (int tg = 0; tg < 4; ++tg)
-            if (!tb[tg].mask_dbg)
-                if (int rc = dalloc(&tb[tg].mask_dbg, (size_t)T * NOUT))
+            if (!sl.ta[tg].mask_dbg)
+                if (int rc = dalloc(&sl.ta[tg].mask_dbg, (size_t)T * NOUT))
                     return rc;
     last_flags = flags;
 
-    UMX_HIP_CHECK(hipEventRecord(ev[ST_STFT], stream));
-    UMX_HIP_CHECK(hipMemsetAsync(maxabs, 0, sizeof(unsigned), stream));
-    hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, stream, audio_dev, n, N, T, window, tw1, tw2, spec,
-                       mix_mag, x, maxabs);
-    UMX_HIP_CHECK(hipEventRecord(ev[ST_FC1], stream));
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_STFT], st));
+    UMX_HIP_CHECK(hipMemsetAsync(sl.maxabs, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev, n, N, T, window, tw1, tw2, sl.spec,
+                       sl.mix_mag, sl.x, sl.maxabs);
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
 
     auto launch_gemm = [&](int mode, int layer) {
         GemmArgs g;
@@ -531,29 +609,30 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
         for (int i = 0; i < nact; ++i)
         {
             const TargetBufs &b = tb[active[i]];
+            const TargetAct &c = sl.ta[active[i]];
             GemmTarget &t = g.t[i];
             switch (mode)
             {
             case G_FC1:
-                t.A = x; t.B = b.fc1_w; t.C = b.cat;
+                t.A = sl.x; t.B = b.fc1_w; t.C = c.cat;
                 t.e0 = b.bn1[0]; t.e1 = b.bn1[1]; t.e2 = b.bn1[2]; t.e3 = b.bn1[3];
                 t.q0 = b.in_scale; t.q1 = b.in_mean;
                 g.N = H; g.K = KX; g.lda = KX; g.ldc = 2 * H;
                 break;
             case G_IH:
-                t.A = layer == 0 ? b.cat : layer == 1 ? b.la : b.lb;
-                t.B = b.ih_w[layer]; t.C = b.P; t.e0 = b.ih_b[layer];
+                t.A = layer == 0 ? c.cat : layer == 1 ? c.la : c.lb;
+                t.B = b.ih_w[layer]; t.C = c.P; t.e0 = b.ih_b[layer];
                 g.N = 4 * H; g.K = H; g.lda = layer == 0 ? 2 * H : H; g.ldc = 4 * H;
                 break;
             case G_FC2:
-                t.A = b.cat; t.B = b.fc2_w; t.C = b.a2;
+                t.A = c.cat; t.B = b.fc2_w; t.C = c.a2;
                 t.e0 = b.bn2[0]; t.e1 = b.bn2[1]; t.e2 = b.bn2[2]; t.e3 = b.bn2[3];
                 g.N = H; g.K = 2 * H; g.lda = 2 * H; g.ldc = H;
                 break;
             default:
-                t.A = b.a2; t.B = b.fc3_w; t.C = b.mag;
+                t.A = c.a2; t.B = b.fc3_w; t.C = c.mag;
                 t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
-                t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = mix_mag; t.dbg = dbg ? b.mask_dbg : nullptr;
+                t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = sl.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
                 g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0;
                 break;
             }
@@ -561,10 +640,10 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
         const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
         switch (mode)
         {
-        case G_FC1: hipLaunchKernelGGL(gemm_tn_kernel<G_FC1>, grid, block, GEMM_LDS_BYTES, stream, g); break;
-        case G_IH: hipLaunchKernelGGL(gemm_tn_kernel<G_IH>, grid, block, GEMM_LDS_BYTES, stream, g); break;
-        case G_FC2: hipLaunchKernelGGL(gemm_tn_kernel<G_FC2>, grid, block, GEMM_LDS_BYTES, stream, g); break;
-        default: hipLaunchKernelGGL(gemm_tn_kernel<G_FC3>, grid, block, GEMM_LDS_BYTES, stream, g); break;
+        case G_FC1: hipLaunchKernelGGL(gemm_tn_kernel<G_FC1>, grid, block, GEMM_LDS_BYTES, st, g); break;
+        case G_IH: hipLaunchKernelGGL(gemm_tn_kernel<G_IH>, grid, block, GEMM_LDS_BYTES, st, g); break;
+        case G_FC2: hipLaunchKernelGGL(gemm_tn_kernel<G_FC2>, grid, block, GEMM_LDS_BYTES, st, g); break;
+        default: hipLaunchKernelGGL(gemm_tn_kernel<G_FC3>, grid, block, GEMM_LDS_BYTES, st, g); break;
         }
     };
 
@@ -573,52 +652,65 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
         launch_gemm(G_FC1, 0);
         for (int layer = 0; layer < 3; ++layer)
         {
-            UMX_HIP_CHECK(hipEventRecord(ev[ST_IH0 + 2 * layer], stream));
+            UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
             launch_gemm(G_IH, layer);
-            UMX_HIP_CHECK(hipEventRecord(ev[ST_LSTM0 + 2 * layer], stream));
-            if (int rc = run_lstm_layer(layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE))
+            if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3); if two
+                           // LSTM grids cannot be co-resident, wait for its last layer instead
+                UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[2 * 8 * S <= lstm_capacity ? layer : 2], 0));
+            UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
+            if (int rc = run_lstm_layer(sl, layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE))
                 return rc;
+            UMX_HIP_CHECK(hipEventRecord(sl.rec_done[layer], st));
         }
-        UMX_HIP_CHECK(hipEventRecord(ev[ST_FC2], stream));
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
         launch_gemm(G_FC2, 0);
-        UMX_HIP_CHECK(hipEventRecord(ev[ST_FC3], stream));
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
         launch_gemm(G_FC3, 0);
     }
     else
     {
         for (int k = ST_IH0; k <= ST_FC3; ++k)
-            UMX_HIP_CHECK(hipEventRecord(ev[k], stream));
+            UMX_HIP_CHECK(hipEventRecord(sl.ev[k], st));
+        for (int l = 0; l < 3; ++l)
+        {
+            if (prev.used)
+                UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[l], 0));
+            UMX_HIP_CHECK(hipEventRecord(sl.rec_done[l], st));
+        }
     }
     for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
         if (flags & UMX_FLAG_SKIP_TARGET(tg))
-            UMX_HIP_CHECK(hipMemsetAsync(tb[tg].mag, 0, sizeof(float) * 2 * T * NBINS, stream));
-    UMX_HIP_CHECK(hipEventRecord(ev[ST_WIENER], stream));
+            UMX_HIP_CHECK(hipMemsetAsync(sl.ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_WIENER], st));
     WienerMags wm;
     for (int s = 0; s < 4; ++s)
-        wm.m[s] = tb[s].mag;
+        wm.m[s] = sl.ta[s].mag;
     const int bt = (NBINS + 255) / 256;
     if (flags & UMX_FLAG_NO_WIENER)
     {
         const size_t nel = (size_t)2 * T * NBINS;
-        hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, stream, spec, wm, T, y);
+        hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, sl.spec, wm, T, sl.y);
     }
     else
     {
-        hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, stream, spec, wm, T, maxabs, wpart,
-                           nbatch);
-        hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, stream, wpart, nbatch, R);
-        hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, stream, spec, wm, T, maxabs, R, y);
+        hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, sl.spec, wm, T, sl.maxabs,
+                           sl.wpart, nbatch);
+        hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, sl.wpart, nbatch, sl.R);
+        hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, sl.spec, wm, T, sl.maxabs, sl.R, sl.y);
     }
-    UMX_HIP_CHECK(hipEventRecord(ev[ST_ISTFT], stream));
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, stream, y, T, window, nw, tw1, tw2, frames);
-    UMX_HIP_CHECK(hipEventRecord(ev[ST_OLA], stream));
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
+    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, sl.y, T, window, nw, tw1, tw2, sl.frames);
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
     OlaOut oo;
     for (int s = 0; s < 4; ++s)
         oo.p[s] = out[s];
-    hipLaunchKernelGGL(istft_ola_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, stream, frames, T, n, oo);
-    UMX_HIP_CHECK(hipEventRecord(ev[ST_COUNT], stream));
+    hipLaunchKernelGGL(istft_ola_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, st, sl.frames, T, n, oo);
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_COUNT], st));
     UMX_HIP_CHECK(hipGetLastError());
-    have_times = true;
+    sl.have_times = true;
+    sl.used = true;
+    cur = si;
+    ++nseg;
     return UMX_OK;
 }
 
@@ -652,15 +744,23 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream)
-        (void)hipStreamSynchronize(ctx->stream);
+    for (int si = 0; si < 2; ++si)
+        if (ctx->slot[si].stream)
+            (void)hipStreamSynchronize(ctx->slot[si].stream);
     for (void *p : ctx->allocs)
         (void)hipFree(p);
-    for (int i = 0; i <= ST_COUNT; ++i)
-        if (ctx->ev[i])
-            (void)hipEventDestroy(ctx->ev[i]);
-    if (ctx->stream)
-        (void)hipStreamDestroy(ctx->stream);
+    for (int si = 0; si < 2; ++si)
+    {
+        Slot &sl = ctx->slot[si];
+        for (int i = 0; i <= ST_COUNT; ++i)
+            if (sl.ev[i])
+                (void)hipEventDestroy(sl.ev[i]);
+        for (int l = 0; l < 3; ++l)
+            if (sl.rec_done[l])
+                (void)hipEventDestroy(sl.rec_done[l]);
+        if (sl.stream)
+            (void)hipStreamDestroy(sl.stream);
+    }
     delete ctx;
 }
 
@@ -672,12 +772,15 @@ int umx_hip_stream_reset(umx_hip_ctx *ctx)
 {
     if (!ctx)
         return UMX_ERR_ARG;
-    hipError_t e = hipMemsetAsync(ctx->state, 0, sizeof(float) * 4 * 12 * ctx->Hl, ctx->stream);
+    if (int rc = ctx->sync_all())
+        return rc;
+    hipError_t e = hipMemset(ctx->state, 0, sizeof(float) * 4 * 12 * ctx->Hl);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
+    ctx->slot[0].used = ctx->slot[1].used = false; // a new track: no cross-segment dependency to wait for
     return UMX_OK;
 }
 
@@ -685,9 +788,9 @@ int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst)
 {
     if (!ctx || !host_dst)
         return UMX_ERR_ARG;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpy(host_dst, ctx->state, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyDeviceToHost);
+    if (int rc = ctx->sync_all())
+        return rc;
+    hipError_t e = hipMemcpy(host_dst, ctx->state, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
@@ -700,14 +803,15 @@ int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src)
 {
     if (!ctx || !host_src)
         return UMX_ERR_ARG;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess)
-        e = hipMemcpy(ctx->state, host_src, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyHostToDevice);
+    if (int rc = ctx->sync_all())
+        return rc;
+    hipError_t e = hipMemcpy(ctx->state, host_src, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
+    ctx->slot[0].used = ctx->slot[1].used = false;
     return UMX_OK;
 }
 
@@ -723,26 +827,27 @@ int umx_hip_sync(umx_hip_ctx *ctx)
 {
     if (!ctx)
         return UMX_ERR_ARG;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess)
+    if (int rc = ctx->sync_all())
+        return rc;
+    for (int si = 0; si < 2; ++si)
     {
-        ctx->set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-        return UMX_ERR_HIP;
-    }
-    unsigned st = 0;
-    e = hipMemcpy(&st, ctx->status, sizeof st, hipMemcpyDeviceToHost);
-    if (e != hipSuccess)
-    {
-        ctx->set_error(hipGetErrorString(e));
-        return UMX_ERR_HIP;
-    }
-    if (st != 0)
-    {
-        ctx->set_error("persistent LSTM kernel timed out waiting for a hidden-state granule at step " +
-                       std::to_string(st - 1));
-        (void)hipMemset(ctx->status, 0, sizeof(unsigned));
-        ctx->persistent_ok = false;
-        return UMX_ERR_TIMEOUT;
+        unsigned st = 0;
+        hipError_t e = hipMemcpy(&st, ctx->slot[si].status, sizeof st, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+        {
+            ctx->set_error(hipGetErrorString(e));
+            return UMX_ERR_HIP;
+        }
+        if (st != 0)
+        {
+            ctx->set_error(st == 0x80000000u
+                               ? std::string("persistent LSTM kernel: grid barrier timed out (grid not co-resident)")
+                               : "persistent LSTM kernel timed out waiting for a hidden-state granule at step " +
+                                     std::to_string(st - 1));
+            (void)hipMemset(ctx->slot[si].status, 0, sizeof(unsigned));
+            ctx->persistent_ok = false;
+            return UMX_ERR_TIMEOUT;
+        }
     }
     return UMX_OK;
 }
@@ -755,8 +860,11 @@ int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, floa
             ctx->set_error("infer_segment: bad arguments");
         return UMX_ERR_ARG;
     }
-    hipError_t e = hipMemcpyAsync(ctx->audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice,
-                                  ctx->stream);
+    // the staging buffers are shared, so the host-pointer form is strictly one segment at a time
+    if (int rc = ctx->sync_all())
+        return rc;
+    hipStream_t st = ctx->slot[ctx->nseg & 1].stream;
+    hipError_t e = hipMemcpyAsync(ctx->audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
@@ -767,8 +875,7 @@ int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, floa
         return rc;
     for (int s = 0; s < 4; ++s)
     {
-        e = hipMemcpyAsync(out_host[s], ctx->out_dev[s], sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost,
-                           ctx->stream);
+        e = hipMemcpyAsync(out_host[s], ctx->out_dev[s], sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess)
         {
             ctx->set_error(hipGetErrorString(e));
@@ -778,7 +885,7 @@ int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, floa
     return umx_hip_sync(ctx);
 }
 
-void *umx_hip_stream_handle(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+void *umx_hip_stream_handle(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->slot[ctx->nseg & 1].stream : nullptr; }
 int umx_hip_nb_frames(const umx_hip_ctx *ctx) { return ctx ? ctx->T : 0; }
 int umx_hip_segment_samples(const umx_hip_ctx *ctx) { return ctx ? ctx->N : 0; }
 int umx_hip_hidden(const umx_hip_ctx *ctx) { return ctx ? ctx->H : 0; }
@@ -789,17 +896,18 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
         return -1;
     const std::string w = what;
     const int T = ctx->T, H = ctx->H;
+    const Slot &sl = ctx->slot[ctx->cur];
     const void *src = nullptr;
     size_t nfl = 0, src_ld = 0, rows = 0, cols = 0; // strided copy when src_ld != cols
-    if (w == "spec") { src = ctx->spec; nfl = (size_t)2 * 2 * T * NBINS; }
-    else if (w == "mix_mag") { src = ctx->mix_mag; nfl = (size_t)2 * T * NBINS; }
-    else if (w == "x") { src = ctx->x; nfl = (size_t)T * KX; }
-    else if (w == "fc1") { src = ctx->tb[target].cat; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
-    else if (w == "lstm") { src = ctx->tb[target].cat + H; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
-    else if (w == "mask") { src = ctx->tb[target].mask_dbg; nfl = (size_t)T * NOUT; }
-    else if (w == "target_mag") { src = ctx->tb[target].mag; nfl = (size_t)2 * T * NBINS; }
-    else if (w == "y") { src = ctx->y + (size_t)target * 2 * T * NBINS; nfl = (size_t)2 * 2 * T * NBINS; }
-    else if (w == "max_abs") { src = ctx->maxabs; nfl = 1; }
+    if (w == "spec") { src = sl.spec; nfl = (size_t)2 * 2 * T * NBINS; }
+    else if (w == "mix_mag") { src = sl.mix_mag; nfl = (size_t)2 * T * NBINS; }
+    else if (w == "x") { src = sl.x; nfl = (size_t)T * KX; }
+    else if (w == "fc1") { src = sl.ta[target].cat; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
+    else if (w == "lstm") { src = sl.ta[target].cat + H; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
+    else if (w == "mask") { src = sl.ta[target].mask_dbg; nfl = (size_t)T * NOUT; }
+    else if (w == "target_mag") { src = sl.ta[target].mag; nfl = (size_t)2 * T * NBINS; }
+    else if (w == "y") { src = sl.y + (size_t)target * 2 * T * NBINS; nfl = (size_t)2 * 2 * T * NBINS; }
+    else if (w == "max_abs") { src = sl.maxabs; nfl = 1; }
     else return -1;
     if (!src)
         return -2;
@@ -807,7 +915,7 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
         return (long)nfl;
     if (cap < nfl)
         return -3;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (ctx->sync_all() != UMX_OK)
         return -4;
     hipError_t e;
     if (rows)
@@ -833,15 +941,16 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
 
 int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap)
 {
-    if (!ctx || !ctx->have_times)
+    if (!ctx)
         return 0;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    Slot &sl = ctx->slot[ctx->cur];
+    if (!sl.have_times || ctx->sync_all() != UMX_OK)
         return 0;
     int n = std::min(cap, (int)ST_COUNT);
     for (int i = 0; i < n; ++i)
     {
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, ctx->ev[i], ctx->ev[i + 1]);
+        (void)hipEventElapsedTime(&t, sl.ev[i], sl.ev[i + 1]);
         if (names)
             names[i] = kStageNames[i];
         if (ms)
@@ -850,15 +959,15 @@ int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap
     return ST_COUNT;
 }
 
-int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx) { return ctx && ctx->last_persistent ? 1 : 0; }
+int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx) { return ctx && ctx->slot[ctx->cur].last_persistent ? 1 : 0; }
 
 int umx_hip_lstm_mode(umx_hip_ctx *ctx)
 {
-    if (!ctx || !ctx->last_persistent)
+    if (!ctx || !ctx->slot[ctx->cur].last_persistent)
         return 0;
     unsigned st[2] = {0, 0};
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(st, ctx->status, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
+    if (ctx->sync_all() != UMX_OK ||
+        hipMemcpy(st, ctx->slot[ctx->cur].status, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
         return -1;
     return st[1] ? 2 : 1;
 }
@@ -867,8 +976,8 @@ int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48)
 {
     if (!ctx || !out48)
         return UMX_ERR_ARG;
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(out48, ctx->lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
+    if (ctx->sync_all() != UMX_OK ||
+        hipMemcpy(out48, ctx->slot[ctx->cur].lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
         return UMX_ERR_HIP;
     return UMX_OK;
 }

@@ -58,15 +58,54 @@ struct LstmArgs
     int force_safe;   // 1 = never use the intra-XCD protocol (testing)
 };
 
-constexpr int LSTM_SYNC_HEADER_WORDS = 16; // census[8], arrivals, pad -> granules start 64-byte aligned
+constexpr int LSTM_SYNC_HEADER_WORDS = 32; // census[8], arrivals, pad -> granules start 128-byte aligned
+#ifndef LSTM_SLICE_STRIDE
+#define LSTM_SLICE_STRIDE 16 // granules (8 B each) between the 16-granule lines of consecutive slices
+#endif
+// granule index of (slot, chain, hidden unit k): one 128-byte line per producer slice, lines spread with
+// LSTM_SLICE_STRIDE so that a chain's lines do not pile up on one L2 channel
+__host__ __device__ inline size_t granule_index(int slot, int chain, int k, int S)
+{
+    return ((size_t)(slot * 8 + chain) * S + (k >> 4)) * LSTM_SLICE_STRIDE + (k & 15);
+}
+__host__ __device__ inline size_t granule_count(int S) { return (size_t)2 * 8 * S * LSTM_SLICE_STRIDE; }
 
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); } // lstm.cpp:36-39
 
+// Activations.  PRECISE = the ROCm device-library expf/tanhf (<= 2 ulp) with IEEE division; the default
+// uses the hardware transcendentals directly (v_exp_f32, v_rcp_f32; ~1e-7 absolute error), which is the
+// same error class as the reference's own Eigen vectorised exp/tanh (generic_fast_tanh_float) and
+// shortens the serial gate phase of every LSTM step by ~500 shader cycles.
+__device__ __forceinline__ float exp_hw(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+// tanh from e = exp(-2|x|): (1 - e) / (1 + e) with the sign of x; |x| < 0.125 uses the odd Taylor polynomial
+// through x^7 (next term < 2e-10 relative) instead, which avoids the 1 - e cancellation
+__device__ __forceinline__ float tanh_from_e(float x, float e, float rcp1pe)
+{
+    const float x2 = x * x;
+    const float big = copysignf((1.0f - e) * rcp1pe, x);
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.0539682540f, 0.133333333f), -0.333333333f), 1.0f);
+    return fabsf(x) < 0.125f ? poly : big;
+}
+__device__ __forceinline__ float tanh_hw(float x)
+{
+    const float e = exp_hw(-2.0f * fabsf(x));
+    return tanh_from_e(x, e, __builtin_amdgcn_rcpf(1.0f + e));
+}
+
 // pre-activation of gate column lane = 4*u + g (all 64 lanes) -> new (c, h), replicated in the quad
-__device__ __forceinline__ void lstm_cell(float pre, int lane, float &c, float &h)
+template <bool PRECISE> __device__ __forceinline__ void lstm_cell(float pre, int lane, float &c, float &h)
 {
     const int g = lane & 3;
-    const float act = (g == 2) ? tanhf(pre) : sigmoid_ref(pre);
+    float act;
+    if (PRECISE)
+        act = (g == 2) ? tanhf(pre) : sigmoid_ref(pre);
+    else
+    {
+        // one v_exp_f32 + one v_rcp_f32 per lane, no divergence: e = exp(-x) (sigmoid lanes) or exp(-2|x|)
+        const float e = exp_hw(g == 2 ? -2.0f * fabsf(pre) : -pre);
+        const float r = __builtin_amdgcn_rcpf(1.0f + e);
+        act = (g == 2) ? tanh_from_e(pre, e, r) : r;
+    }
     const int ai = __float_as_int(act);
     const float i_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, true)); // quad_perm [0,0,0,0]
     const float f_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, true)); // [1,1,1,1]
@@ -74,7 +113,23 @@ __device__ __forceinline__ void lstm_cell(float pre, int lane, float &c, float &
     const float o_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, true)); // [3,3,3,3]
     const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
     c = c_t;
-    h = o_t * tanhf(c_t); // lstm.cpp:157
+    h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
+}
+
+// row_ror:n of a 32-bit value (rotation inside each row of 16 lanes); n is a compile-time constant
+template <int N> __device__ __forceinline__ int dpp_row_ror(int v)
+{
+    if (N == 0)
+        return v;
+    return __builtin_amdgcn_mov_dpp(v, 0x120 + (N & 15), 0xF, 0xF, true);
+}
+// +1 if row_ror:1 makes lane i read lane i+1, -1 if it reads lane i-1 (self-calibrating: the step
+// driver must walk k in the same order as the persistent kernel's DPP rotations)
+__device__ __forceinline__ int dpp_ror_direction()
+{
+    const int lane = threadIdx.x & 63;
+    const int src = dpp_row_ror<1>(lane);
+    return (((src - lane) & 15) == 1) ? 1 : -1;
 }
 
 __device__ __forceinline__ size_t state_off(int target, int layer, int dir, int hc, int Hl)
@@ -84,7 +139,11 @@ __device__ __forceinline__ size_t state_off(int target, int layer, int dir, int 
 
 // ------------------------------------------------------------------ per-step driver
 // grid (S, chains); hbuf[step&1] holds h_{t-1}, hbuf[(step+1)&1] receives h_t; c lives in state.
-__global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmArgs a, int step)
+// The k summation order mirrors the persistent kernel exactly (bitwise-identical results):
+//   Hl == 512: per wave four row-partials p_r over k = 64w + 16r + ((u + dir*n) & 15), n = 0..15
+//              (the DPP rotation order), combined as (p0 + p2) + (p1 + p3);
+//   otherwise: even-k / odd-k partial sums (the v_pk_fma_f32 order).
+template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmArgs a, int step)
 {
     __shared__ float hs[1024];
     __shared__ float part[8][64];
@@ -98,31 +157,50 @@ __global__ __launch_bounds__(LSTM_THREADS) void lstm_step_kernel(LstmArgs a, int
         hs[i] = hprev[i];
     __syncthreads();
     const int kpw = Hl >> 3;
-    const float *Wp = a.W + (((size_t)wchain * a.S + slice) * Hl + (size_t)w * kpw) * 64 + l;
-    float2v acc = {0.f, 0.f}; // even-k / odd-k partial sums, same order as the persistent kernel
-    for (int i = 0; i < kpw; i += 2)
+    const float *Wc = a.W + ((size_t)wchain * a.S + slice) * Hl * 64 + l; // column l, stride 64 per k
+    float partial;
+    if (kpw == 64)
     {
-        float2v wv, hv;
-        wv.x = Wp[(size_t)i * 64];
-        wv.y = Wp[(size_t)(i + 1) * 64];
-        hv.x = hs[w * kpw + i];
-        hv.y = hs[w * kpw + i + 1];
-        acc = __builtin_elementwise_fma(wv, hv, acc);
+        const int rdir = dpp_ror_direction(), u = l >> 2;
+        float pr[4];
+        for (int r = 0; r < 4; ++r)
+        {
+            float acc = 0.f;
+            for (int n = 0; n < 16; ++n)
+            {
+                const int k = 64 * w + 16 * r + ((u + rdir * n) & 15);
+                acc = fmaf(Wc[(size_t)k * 64], hs[k], acc);
+            }
+            pr[r] = acc;
+        }
+        partial = (pr[0] + pr[2]) + (pr[1] + pr[3]);
     }
-    part[w][l] = acc.x + acc.y;
+    else
+    {
+        float2v acc = {0.f, 0.f};
+        for (int i = 0; i < kpw; i += 2)
+        {
+            float2v wv, hv;
+            wv.x = Wc[(size_t)(w * kpw + i) * 64];
+            wv.y = Wc[(size_t)(w * kpw + i + 1) * 64];
+            hv.x = hs[w * kpw + i];
+            hv.y = hs[w * kpw + i + 1];
+            acc = __builtin_elementwise_fma(wv, hv, acc);
+        }
+        partial = acc.x + acc.y;
+    }
+    part[w][l] = partial;
     __syncthreads();
     if (w == 0)
     {
-        float s = part[0][l];
-#pragma unroll
-        for (int ww = 1; ww < 8; ++ww)
-            s += part[ww][l];
+        const float s = ((part[0][l] + part[1][l]) + (part[2][l] + part[3][l])) +
+                        ((part[4][l] + part[5][l]) + (part[6][l] + part[7][l]));
         const float p = a.P[target][(size_t)t * a.ldp + ((size_t)dir * a.S + slice) * 64 + l];
         const float pre = (p + s) + a.bhh[((size_t)wchain * a.S + slice) * 64 + l]; // lstm.cpp:132-140
         const int unit = slice * 16 + (l >> 2);
         float *cst = a.state + state_off(target, a.layer, dir, 1, Hl);
         float c = cst[unit], h;
-        lstm_cell(pre, l, c, h);
+        lstm_cell<PRECISE>(pre, l, c, h);
         if ((l & 3) == 0)
         {
             cst[unit] = c;
@@ -152,6 +230,12 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then abort the launch
+#ifndef LSTM_POLLS_IN_FLIGHT
+#define LSTM_POLLS_IN_FLIGHT 3
+#endif
+#ifndef LSTM_POLL_DELAY
+#define LSTM_POLL_DELAY 8 // x64 shader cycles a dot wave sleeps after the barrier before its first poll
+#endif
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -175,7 +259,36 @@ __device__ __forceinline__ unsigned long long granule_load(gu64 *p)
 }
 
 // KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64, even.
-template <int KPW, bool FAST>
+template <int N> struct DotDpp
+{
+    // acc[cc] += W[N][cc] * h(rotated by N lanes inside the row), for N = 15 .. 0 recursively
+    static __device__ __forceinline__ void run(const float (&W)[16][4], int hbits, float (&acc)[4])
+    {
+        DotDpp<N - 1>::run(W, hbits, acc);
+        const float hr = __int_as_float(dpp_row_ror<N>(hbits));
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            acc[cc] = fmaf(W[N][cc], hr, acc[cc]);
+    }
+};
+template <> struct DotDpp<-1>
+{
+    static __device__ __forceinline__ void run(const float (&)[16][4], int, float (&)[4]) {}
+};
+template <int N> struct KidxDpp
+{
+    static __device__ __forceinline__ void run(int lane_k, int (&kidx)[16])
+    {
+        KidxDpp<N - 1>::run(lane_k, kidx);
+        kidx[N] = dpp_row_ror<N>(lane_k);
+    }
+};
+template <> struct KidxDpp<-1>
+{
+    static __device__ __forceinline__ void run(int, int (&)[16]) {}
+};
+
+template <int KPW, bool FAST, bool PRECISE>
 __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chain, int slice, float (*part)[8][64],
                                                       int *abort_flag)
 {
@@ -185,8 +298,36 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     constexpr int Hl = KPW * 8;
     const int T = a.T;
 
-    // W_hh slice -> registers, once: pairs (k even, k odd) feed v_pk_fma_f32
-    float2v W[KPW / 2];
+    // W_hh slice -> registers, once.
+    // KPW == 64 ("DPP" layout): lane (j = l & 15, r = l >> 4) owns the 4 gate columns of unit j and the
+    //   16 k of row r: Wd[n][cc] = W[k_n][4j + cc] where k_n is the k whose h this lane sees after
+    //   row_ror:n of the polled h vector (self-calibrated with the same DPP op) -> 64 v_fmac_f32_dpp
+    //   per step, no lane->SGPR broadcast at all.
+    // otherwise ("readlane" layout): lane l owns gate column l and all KPW k of the wave: pairs
+    //   (k even, k odd) feed v_pk_fma_f32 with an SGPR pair from v_readlane.
+    constexpr bool DPP = (KPW == 64);
+    float2v W[KPW / 2]; // dead in the DPP instantiation
+    float Wd[16][4];    // dead in the readlane instantiations
+    if (w >= 8)
+    {
+        // gate wave: no weights
+    }
+    else if constexpr (DPP)
+    {
+        int kidx[16];
+        KidxDpp<15>::run(w * KPW + l, kidx);
+        const float *Wb = a.W + ((size_t)wchain * a.S + slice) * Hl * 64 + 4 * (l & 15);
+#pragma unroll
+        for (int n = 0; n < 16; ++n)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(Wb + (size_t)kidx[n] * 64);
+            Wd[n][0] = v.x;
+            Wd[n][1] = v.y;
+            Wd[n][2] = v.z;
+            Wd[n][3] = v.w;
+        }
+    }
+    else
     {
         const float *Wp = a.W + (((size_t)wchain * a.S + slice) * Hl + (size_t)w * KPW) * 64 + l;
 #pragma unroll
@@ -196,75 +337,129 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             W[i].y = Wp[(size_t)(2 * i + 1) * 64];
         }
     }
-    const float bh = a.bhh[((size_t)wchain * a.S + slice) * 64 + l];
+    // Wave roles: waves 0..7 poll h, multiply their k-range and leave 64 partial sums in LDS; wave 8
+    // (the "gate wave") owns c, adds the 8 partials, applies the gates and publishes the 16 new h.
+    // One barrier per step.  Keeping the gates out of the dot waves matters: a wave that computed the
+    // gates would start polling ~650 cycles after the others and miss a whole L2 round trip every step.
+    // blockDim 576: dedicated gate wave 8; blockDim 512: wave 0 also applies the gates (two such
+    // workgroups fit one CU, which the cross-segment pipeline of engine.hip relies on)
+    const int gw = (blockDim.x > 512) ? 8 : 0;
+    const bool gate_wave = (w == gw), dot_wave = (w < 8);
+    const float bh = gate_wave ? a.bhh[((size_t)wchain * a.S + slice) * 64 + l] : 0.f;
     const int unit = slice * 16 + (l >> 2);
     float c = 0.f;
-    if (w == 0)
+    if (gate_wave)
         c = a.state[state_off(target, a.layer, dir, 1, Hl) + unit];
     // h_{-1}: this wave's k-range, one value per lane (lanes >= KPW idle)
     float hval = 0.f;
-    if (l < KPW)
+    if (dot_wave && l < KPW)
         hval = a.state[state_off(target, a.layer, dir, 0, Hl) + w * KPW + l];
 
     gu64 *gran = (gu64 *)(a.sync + LSTM_SYNC_HEADER_WORDS);
     gu32 *status = (gu32 *)a.status;
     const float *Pp = a.P[target] + ((size_t)dir * a.S + slice) * 64 + l;
     float hlast = 0.f;
-    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && l == 0 && w < 2;
+    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && l == 0 && (w == gw || w == 1);
     unsigned long long pc[5] = {0, 0, 0, 0, 0};
 
     for (int step = 0; step < T; ++step)
     {
         const int t = dir == 0 ? step : T - 1 - step;
-        float p = 0.f;
-        if (w == 0)
-            p = Pp[(size_t)t * a.ldp]; // issued before the poll: latency hides behind it
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (prof)
             c0 = clock64();
-        if (step > 0)
+        float p = 0.f;
+        if (gate_wave)
+            p = Pp[(size_t)t * a.ldp]; // issued a whole step ahead of its use
+        if (dot_wave)
         {
-            // wait for h_{step-1}: tag == step, slot (step-1)&1
-            gu64 *g = gran + ((size_t)((step - 1) & 1) * 8 + chain) * Hl + w * KPW + l;
-            const unsigned want = (unsigned)step;
-            bool ok = (l >= KPW);
-            unsigned long long x = 0;
-            unsigned spins = 0;
-            for (;;)
+            if (step > 0)
             {
-                if (!ok)
+                // wait for h_{step-1}: tag == step, slot (step-1)&1.  A granule keeps its tag until it is
+                // overwritten two steps later, so every lane reloads until one poll shows all tags.
+                gu64 *g = gran + granule_index((step - 1) & 1, chain, w * KPW + (l < KPW ? l : 0), a.S);
+                const unsigned want = (unsigned)step;
+                // The gate wave needs ~600 cycles before anything can change: sleep through that, then keep
+                // three polls in flight so the poll period is a third of the L2 round trip (the step time is
+                // a maximum over ~2000 polling waves: the quantisation is paid almost in full every step).
+                if (FAST && !gate_wave)
+                    __builtin_amdgcn_s_sleep(LSTM_POLL_DELAY);
+                unsigned long long x = granule_load(g), xb = 0, xc = 0;
+                if (LSTM_POLLS_IN_FLIGHT >= 2)
+                    xb = granule_load(g);
+                if (LSTM_POLLS_IN_FLIGHT >= 3)
+                    xc = granule_load(g);
+                unsigned spins = 0;
+                for (;;)
                 {
-                    x = granule_load(g);
-                    ok = (unsigned)(x >> 32) == want;
+                    if (__all((unsigned)(x >> 32) == want))
+                        break;
+                    if (LSTM_POLLS_IN_FLIGHT >= 3)
+                    {
+                        x = xb;
+                        xb = xc;
+                        xc = granule_load(g);
+                    }
+                    else if (LSTM_POLLS_IN_FLIGHT == 2)
+                    {
+                        x = xb;
+                        xb = granule_load(g);
+                    }
+                    else
+                        x = granule_load(g);
+                    if (++spins > LSTM_SPIN_LIMIT ||
+                        ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                    {
+                        if (l == 0)
+                            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *abort_flag = 1;
+                        break;
+                    }
+                    if (!FAST)
+                        __builtin_amdgcn_s_sleep(1);
                 }
-                if (__all(ok))
-                    break;
-                if (++spins > LSTM_SPIN_LIMIT ||
-                    ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-                {
-                    if (l == 0)
-                        __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *abort_flag = 1;
-                    break;
-                }
-                if (!FAST)
-                    __builtin_amdgcn_s_sleep(1);
+                hval = __uint_as_float((unsigned)x);
             }
-            hval = __uint_as_float((unsigned)x);
-        }
-        if (prof)
-            c1 = clock64();
-        // partial dot product over this wave's k-range, h broadcast lane -> SGPR pair
-        float2v acc = {0.f, 0.f};
+            if (prof)
+                c1 = clock64();
+            if constexpr (DPP)
+            {
+                // 16 in-row rotations x 4 columns, 4 independent accumulators
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                DotDpp<15>::run(Wd, __float_as_int(hval), acc);
+                // rows r and r+2 meet through v_permlane32_swap (lanes l <-> l+32), rows r and r^1 through a
+                // 16-lane swizzle: lane rows {0,1} end with gates 0 and 2, rows {2,3} with gates 1 and 3
+                float s0, s1;
+                {
+                    const auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[1]), false, false);
+                    const auto r23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[2]), __float_as_uint(acc[3]), false, false);
+                    s0 = __uint_as_float(r01[0]) + __uint_as_float(r01[1]); // p_r + p_{r+2}
+                    s1 = __uint_as_float(r23[0]) + __uint_as_float(r23[1]);
+                }
+                const float t0 = s0 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s0), 0x401F)); // xor 16
+                const float t1 = s1 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s1), 0x401F));
+                if ((l & 16) == 0) // rows 0 and 2 write; rows 1 and 3 hold the same sums
+                {
+                    float *pp = &(*(part + (step & 1)))[w][4 * (l & 15) + (l >> 5)];
+                    pp[0] = t0;
+                    pp[2] = t1;
+                }
+            }
+            else
+            {
+                // partial dot product over this wave's k-range, h broadcast lane -> SGPR pair
+                float2v acc = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < KPW / 2; ++i)
-        {
-            float2v hk;
-            hk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i));
-            hk.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i + 1));
-            acc = __builtin_elementwise_fma(W[i], hk, acc);
+                for (int i = 0; i < KPW / 2; ++i)
+                {
+                    float2v hk;
+                    hk.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i));
+                    hk.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i + 1));
+                    acc = __builtin_elementwise_fma(W[i], hk, acc);
+                }
+                (*(part + (step & 1)))[w][l] = acc.x + acc.y;
+            }
         }
-        (*(part + (step & 1)))[w][l] = acc.x + acc.y;
         if (prof)
             c2 = clock64();
         __syncthreads();
@@ -272,20 +467,18 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             return;
         if (prof)
             c3 = clock64();
-        if (w == 0)
+        if (gate_wave)
         {
-            float s = (*(part + (step & 1)))[0][l];
-#pragma unroll
-            for (int ww = 1; ww < 8; ++ww)
-                s += (*(part + (step & 1)))[ww][l];
+            float(*pq)[64] = *(part + (step & 1));
+            const float s = ((pq[0][l] + pq[1][l]) + (pq[2][l] + pq[3][l])) + ((pq[4][l] + pq[5][l]) + (pq[6][l] + pq[7][l]));
             const float pre = (p + s) + bh;
             float h;
-            lstm_cell(pre, l, c, h);
+            lstm_cell<PRECISE>(pre, l, c, h);
             if ((l & 3) == 0)
             {
                 const unsigned long long gv =
                     ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(h);
-                granule_store<FAST>(gran + ((size_t)(step & 1) * 8 + chain) * Hl + unit, gv);
+                granule_store<FAST>(gran + granule_index(step & 1, chain, unit, a.S), gv);
                 a.out[target][(size_t)t * a.ldo + a.col0 + dir * Hl + unit] = h;
                 hlast = h;
             }
@@ -293,25 +486,25 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         if (prof)
         {
             const long long c4 = clock64();
-            pc[0] += (unsigned long long)(c1 - c0); // poll
+            pc[0] += (unsigned long long)(c1 - c0); // poll (dot waves)
             pc[1] += (unsigned long long)(c2 - c1); // dot
-            pc[2] += (unsigned long long)(c3 - c2); // barrier
-            pc[3] += (unsigned long long)(c4 - c3); // gates + publish (wave 0) / nothing (wave 1)
+            pc[2] += (unsigned long long)(c3 - c2); // barrier wait
+            pc[3] += (unsigned long long)(c4 - c3); // gates + publish (gate wave)
             pc[4] += 1;
         }
     }
-    if (w == 0 && (l & 3) == 0) // lstm.cpp:160-161: the state carries into the next segment
+    if (gate_wave && (l & 3) == 0) // lstm.cpp:160-161: the state carries into the next segment
     {
         a.state[state_off(target, a.layer, dir, 0, Hl) + unit] = hlast;
         a.state[state_off(target, a.layer, dir, 1, Hl) + unit] = c;
     }
     if (prof)
         for (int i = 0; i < 5; ++i)
-            a.prof[(a.layer * 2 + w) * 8 + i] = pc[i];
+            a.prof[(a.layer * 2 + (w == gw ? 0 : 1)) * 8 + i] = pc[i];
 }
 
 // grid = 8*S workgroups (1-D), cooperative launch.  Roles come from the census (see file header).
-template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persistent_kernel(LstmArgs a)
+template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_THREADS) void lstm_persistent_kernel(LstmArgs a)
 {
     __shared__ float part[2][8][64];
     __shared__ int s_ctl[4]; // chain, slice, fast, abort
@@ -353,9 +546,9 @@ template <int KPW> __global__ __launch_bounds__(LSTM_THREADS) void lstm_persiste
     if (s_ctl[3] || chain >= a.nchains) // aborted, or an XCD / block range with no chain to run
         return;
     if (s_ctl[2])
-        lstm_persistent_body<KPW, true>(a, chain, slice, part, &s_ctl[3]);
+        lstm_persistent_body<KPW, true, PRECISE>(a, chain, slice, part, &s_ctl[3]);
     else
-        lstm_persistent_body<KPW, false>(a, chain, slice, part, &s_ctl[3]);
+        lstm_persistent_body<KPW, false, PRECISE>(a, chain, slice, part, &s_ctl[3]);
 }
 
 } // namespace umx
