@@ -127,23 +127,11 @@ def main():
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    stage_acc = {}
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    import importlib
+    mg = importlib.import_module("umx_cpp_amd.multigpu")
+    # W untimed warm-up steps, barrier + synchronize on both sides of exactly K steps, MAX over ranks
+    dt = mg.timed_region(step, fence, args.steps, args.warmup, dist=dist if world > 1 else None, world=world, device=dev)
     # per-stage device time, from hipEvents on the engine's own streams: taken from extra segments run one
     # at a time AFTER the timed region (in the timed region consecutive segments overlap, so a stage's
     # event span there includes the other slot's kernels)

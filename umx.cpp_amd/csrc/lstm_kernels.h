@@ -230,8 +230,11 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then abort the launch
+#ifndef LSTM_SETPRIO
+#define LSTM_SETPRIO 0 // measured: no effect on MI355X with GEMM waves of the other slot co-resident
+#endif
 #ifndef LSTM_POLLS_IN_FLIGHT
-#define LSTM_POLLS_IN_FLIGHT 3
+#define LSTM_POLLS_IN_FLIGHT 1 // measured best once two LSTM grids share the chip (2: -3 %, 3: -5 %)
 #endif
 #ifndef LSTM_POLL_DELAY
 #define LSTM_POLL_DELAY 8 // x64 shader cycles a dot wave sleeps after the barrier before its first poll
@@ -510,6 +513,11 @@ template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_TH
     __shared__ int s_ctl[4]; // chain, slice, fast, abort
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, S = a.S;
+#if LSTM_SETPRIO
+    // latency-critical waves: win issue arbitration against co-resident GEMM / streaming waves of the
+    // other pipeline slot (those are throughput-bound and lose little)
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if (tid == 0)
     {
         gu32 *census = (gu32 *)a.sync;
