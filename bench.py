@@ -132,17 +132,20 @@ def main():
     mg = importlib.import_module("umx_cpp_amd.multigpu")
     # W untimed warm-up steps, barrier + synchronize on both sides of exactly K steps, MAX over ranks
     dt = mg.timed_region(step, fence, args.steps, args.warmup, dist=dist if world > 1 else None, world=world, device=dev)
-    # per-stage device time, from hipEvents on the engine's own streams: taken from extra segments run one
-    # at a time AFTER the timed region (in the timed region consecutive segments overlap, so a stage's
-    # event span there includes the other slot's kernels)
-    pipelined_ms = dt / args.steps * 1e3
+    # per-stage device time from hipEvents on the engine's own streams.  (a) the last two segments of the
+    # timed region (one per pipeline slot; consecutive segments overlap there, so a span includes the other
+    # slot's kernels -- this is the duration rocprofv3 reports for the same command); (b) three extra
+    # segments run one at a time after the timed region (the kernel alone on the chip).
+    st = [eng.stage_times(slot=i) for i in (0, 1)]
+    st = [d for d in st if d]
+    stage_ms = {k: sum(d[k] for d in st) / len(st) for k in st[0]} if st else {}
     serial = []
     for _ in range(3):
         t1 = time.perf_counter()
         step()
         eng.sync()
         serial.append((time.perf_counter() - t1) * 1e3)
-        stage_ms = eng.stage_times()
+        stage_alone_ms = eng.stage_times()
     serial_ms = min(serial)
     finite = bool(all(torch.isfinite(o).all().item() for o in outs))
 
@@ -155,14 +158,31 @@ def main():
             sum(stage_ms.get(f"lstm_ih{l}", 0.0) for l in range(3))
         gemm_flops = gemm["fc1"] + 3 * gemm["lstm_ih"] + gemm["fc2"] + gemm["fc3_mask"]
         # dominant kernel by device time
+        lstm_alone_ms = sum(stage_alone_ms.get(f"lstm_rec{l}", 0.0) for l in range(3))
         if lstm_ms >= gemm_ms:
-            # serial recurrence: fp32 FMA work priced against the f32 peak (it is latency-bound: 3*T
-            # dependent steps; DESIGN.md gives the step-latency view of the same number)
-            ach = 3 * rec / (lstm_ms * 1e-3) / 1e12
-            roofline = {"kernel": "lstm_persistent_kernel" if eng.lstm_was_persistent() else "lstm_step_kernel",
+            # The recurrence is neither HBM- nor MFMA-bound: it is 3*T serially dependent steps whose floor is
+            # the cross-CU hand-off latency.  The schema wants hbm|mfma, so its fp32 FMA
+            # work is priced against the f32 peak; the HBM and latency views are given next to it.
+            per_launch_flops = rec
+            per_launch_ms = lstm_ms / 3
+            ach = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
+            alg_bytes = 4.0 * (4 * T * 4 * H + 8 * (H // 2) * (2 * H) + 8 * 2 * H + 4 * T * H)  # P + W_hh + b_hh + out
+            traffic = None
+            if H == 1024 and T == 2584 and eng.lstm_mode() >= 1:
+                # profiles/r01_v2_pmc_fetch_write_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
+                # passes), KB per launch; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section)
+                traffic = (2 * 99207.9 + 41456.0) * 1024
+            roofline = {"kernel": "lstm_persistent_kernel<64>" if eng.lstm_was_persistent() else "lstm_step_kernel",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(ach / F32_MFMA_PEAK_TF, 5), "traffic": None,
-                        "us_per_step": round(lstm_ms * 1e3 / (3 * T), 3), "serial_steps": 3 * T}
+                        "frac": round(ach / F32_MFMA_PEAK_TF, 5), "traffic": traffic,
+                        "launch_ms": round(per_launch_ms, 4), "launch_ms_alone": round(lstm_alone_ms / 3, 4),
+                        "algorithmic_flops_per_launch": per_launch_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                        "hbm_view": {"achieved_GBs": round(alg_bytes / (per_launch_ms * 1e-3) / 1e9, 1),
+                                     "peak_GBs": HBM_PEAK_GBS,
+                                     "frac": round(alg_bytes / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                        "latency_view": {"serial_steps_per_launch": T, "us_per_step": round(per_launch_ms * 1e3 / T, 3),
+                                         "us_per_step_alone": round(lstm_alone_ms * 1e3 / (3 * T), 3),
+                                         "handoff_floor_us": 0.25}}
         else:
             ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
             roofline = {"kernel": "gemm_tn_kernel", "bound": "mfma", "achieved": round(ach, 3),
@@ -186,6 +206,7 @@ def main():
                        "sharding": f"{world} independent segments (one per rank)"},
             "roofline": roofline,
             "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stages_ms_unpipelined": {k: round(v, 4) for k, v in stage_alone_ms.items()},
             "ms_per_segment_unpipelined": round(serial_ms, 3),
             "gemm_tflops": round(gemm_tf, 2) if gemm_tf else None,
             "streaming_gbs": round(stream_gbs, 1) if stream_gbs else None,

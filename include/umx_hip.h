@@ -107,6 +107,9 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
 /* Per-stage device time of the LAST segment, measured with hipEvents on the context's stream.
  * names/ms are filled up to `cap` entries; returns the number of stages. */
 int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap);
+/* Same for pipeline slot 0 or 1 (consecutive segments alternate slots; when two segments were queued
+ * back to back their spans overlap, so a stage's time includes interference from the other slot). */
+int umx_hip_stage_times_slot(umx_hip_ctx *ctx, int slot_index, const char **names, float *ms, int cap);
 /* 1 if the LSTM layers of the last segment ran in the persistent (one launch per layer) kernel,
  * 0 if the per-timestep driver was used (flag, unsupported hidden size, or grid not co-resident). */
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);

@@ -88,6 +88,7 @@ def hip_lib():
     lib.umx_hip_read_tap.restype = C.c_long
     lib.umx_hip_read_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _fp, C.c_size_t]
     lib.umx_hip_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), _fp, C.c_int]
+    lib.umx_hip_stage_times_slot.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _fp, C.c_int]
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
@@ -99,6 +100,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_destroy", "umx_hip_last_error", "umx_h
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
+               "umx_hip_stage_times_slot",
                "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile"]
 
 
@@ -233,10 +235,13 @@ class Engine:
             return buf.reshape(T, NOUT)
         return buf
 
-    def stage_times(self):
+    def stage_times(self, slot=None):
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()
-        n = self.lib.umx_hip_stage_times(self.h, names, ms, 32)
+        if slot is None:
+            n = self.lib.umx_hip_stage_times(self.h, names, ms, 32)
+        else:
+            n = self.lib.umx_hip_stage_times_slot(self.h, slot, names, ms, 32)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
 
 

@@ -939,11 +939,17 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
     return (long)nfl;
 }
 
+int umx_hip_stage_times_slot(umx_hip_ctx *ctx, int slot_index, const char **names, float *ms, int cap);
 int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap)
 {
-    if (!ctx)
+    return ctx ? umx_hip_stage_times_slot(ctx, ctx->cur, names, ms, cap) : 0;
+}
+
+int umx_hip_stage_times_slot(umx_hip_ctx *ctx, int slot_index, const char **names, float *ms, int cap)
+{
+    if (!ctx || slot_index < 0 || slot_index > 1)
         return 0;
-    Slot &sl = ctx->slot[ctx->cur];
+    Slot &sl = ctx->slot[slot_index];
     if (!sl.have_times || ctx->sync_all() != UMX_OK)
         return 0;
     int n = std::min(cap, (int)ST_COUNT);
