@@ -136,6 +136,7 @@ def main():
     # timed region (one per pipeline slot; consecutive segments overlap there, so a span includes the other
     # slot's kernels -- this is the duration rocprofv3 reports for the same command); (b) three extra
     # segments run one at a time after the timed region (the kernel alone on the chip).
+    prof_pipelined = eng.lstm_profile() if args.lstm_profile else None
     st = [eng.stage_times(slot=i) for i in (0, 1)]
     st = [d for d in st if d]
     stage_ms = {k: sum(d[k] for d in st) / len(st) for k in st[0]} if st else {}
@@ -220,6 +221,12 @@ def main():
         print(json.dumps(line), flush=True)
         if args.lstm_profile:
             pr = eng.lstm_profile()
+            if eng.lstm_mode() >= 1 and H == 1024 and not args.stepwise_lstm:
+                for wi, wn in ((0, "wave 0 (gate duty set 0)"), (1, "wave 3")):
+                    c = prof_pipelined.reshape(6, 8)[wi]
+                    n = max(int(c[4]), 1)
+                    print(f"# wavefront kernel {wn}: cycles/task poll {c[0] / n:.0f} dot {c[1] * 3 / (2 if wi == 0 else 3) / n:.0f} "
+                          f"gate_wait {c[2] * 3 / n:.0f} gates+dot {c[3] * 3 / n:.0f} (tasks {int(c[4])})", file=sys.stderr)
             for layer in range(3):
                 for w in range(2):
                     c = pr[layer, w]

@@ -63,6 +63,11 @@ def hip_lib():
     global _hip
     if _hip is not None:
         return _hip
+    try:  # if torch is going to be used in this process it must bring ITS HIP runtime in first: loading
+        import torch  # the system libamdhip64 before torch's own copy makes torch report "No HIP GPUs"
+        torch.cuda.is_available()
+    except Exception:  # noqa: BLE001 - torch is optional plumbing
+        pass
     path = Path(os.environ.get("UMX_HIP_LIB", HERE / "libumx_hip.so"))  # override = kernel-variant A/B runs
     if not path.exists():
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -223,6 +228,11 @@ class Engine:
         if got != n:
             raise UmxError(ERR_HIP, f"tap {what!r} failed ({got})")
         T, H = self.T, self.hidden
+        what = what.split("@")[0]
+        if what in ("lstm_l0", "lstm_l1"):
+            return buf.reshape(T, H)
+        if what == "proj":
+            return buf.reshape(T, 4 * H)
         if what in ("spec", "y"):
             return buf.view(np.complex64).reshape(2, T, NB)
         if what in ("mix_mag", "target_mag"):

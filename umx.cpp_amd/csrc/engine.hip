@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -17,6 +18,7 @@
 #include "common.h"
 #include "gemm_kernels.h"
 #include "lstm_kernels.h"
+#include "lstm_wavefront.h"
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
 
@@ -74,7 +76,12 @@ struct Slot
     unsigned long long *lprof = nullptr;
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t rec_done[3] = {}; // LSTM layer l of this slot's segment has finished (state updated)
+    hipEvent_t front_done = nullptr, back_done = nullptr; // wavefront mode
     bool have_times = false, last_persistent = false, used = false;
+    // wavefront mode: the segment living in this slot
+    float *job_out[4] = {};
+    int job_n = 0, job_stage = -1; // -1 free, l = waiting for LSTM layer l (0..2)
+    unsigned job_flags = 0;
 };
 } // namespace
 
@@ -89,7 +96,24 @@ struct umx_hip_ctx
     float2 *tw1 = nullptr, *tw2 = nullptr;
     float *audio_in = nullptr, *out_dev[4] = {};
     float *state = nullptr;
-    Slot slot[2];
+    Slot slot[3];             // 2 used in "slots" mode, 3 in "wavefront" mode
+    int nslots = 2;
+    bool wavefront = false;   // one fused LSTM launch per segment for 3 consecutive segments (Hl = 512)
+    bool last_was_wavefront = false;
+    hipStream_t main_stream = nullptr, back_stream = nullptr; // wavefront mode (front work runs on slot.stream)
+    hipEvent_t lstm_ev[3] = {};
+    long long nlaunch = 0;
+    unsigned tag_epoch = 0;   // persistent LSTM launches so far (granule tags are unique per launch)
+    unsigned next_tag_base()
+    {
+        // 4096 tags per launch (T + 1 <= 4096 is checked at create); wraps after ~1M launches, where one
+        // stale line from exactly 2^20 launches ago would have to survive in an L2 -- every buffer is
+        // zeroed at that point anyway (see run_lstm_layer / wf_launch)
+        tag_epoch = (tag_epoch + 1) & 0xFFFFF;
+        return tag_epoch << 12;
+    }
+    unsigned *wf_sync = nullptr, *wf_status = nullptr;
+    size_t wf_sync_words = 0;
     int cur = 0;              // slot of the most recently queued segment
     long long nseg = 0;       // segments queued since creation
     size_t lsync_words = 0;
@@ -123,6 +147,19 @@ struct umx_hip_ctx
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
     int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise);
     int sync_all();
+    void launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
+    int stage_front(Slot &sl, hipStream_t st, const float *audio_dev, int n, const int *active, int nact);
+    int stage_back(Slot &sl, hipStream_t st, float *const out[4], int n, unsigned flags, const int *active, int nact);
+    int wf_enqueue(const float *audio_dev, int n, float *const out[4], unsigned flags);
+    int wf_launch(bool new_segment);
+    int wf_flush();
+    static void active_list(unsigned flags, int *active, int &nact)
+    {
+        nact = 0;
+        for (int tg = 0; tg < 4; ++tg)
+            if (!(flags & UMX_FLAG_SKIP_TARGET(tg)))
+                active[nact++] = tg;
+    }
 };
 
 // ---------------------------------------------------------------- weights
@@ -164,9 +201,9 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         set_error("hidden_size must be a positive multiple of 128 (<= 2048)");
         return UMX_ERR_ARG;
     }
-    if (segment_samples < NFFT)
+    if (segment_samples < NFFT || segment_samples / HOP + 2 > 4096)
     {
-        set_error("segment_samples must be >= 4096");
+        set_error("segment_samples must be in [4096, 4,190,000] (at most 4094 STFT frames per segment)");
         return UMX_ERR_ARG;
     }
     int ndev = 0;
@@ -381,7 +418,14 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     lsync_words = LSTM_SYNC_HEADER_WORDS + granule_count(S) * 2;
     if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
         lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
-    for (int si = 0; si < 2; ++si)
+    // default: two pipeline slots with one LSTM launch per layer ("slots").  UMX_PIPELINE=wavefront selects
+    // the fused three-segment LSTM launches of lstm_wavefront.h (Hl = 512 only; exact but measured slower)
+    wavefront = false;
+    if (const char *e = getenv("UMX_PIPELINE"))
+        if (std::string(e) == "wavefront" && Hl == LSTM_WF_HL)
+            wavefront = true;
+    nslots = wavefront ? 3 : 2;
+    for (int si = 0; si < nslots; ++si)
     {
         Slot &sl = slot[si];
         UMX_HIP_CHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
@@ -429,6 +473,27 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             UMX_HIP_CHECK(hipEventCreate(&sl.ev[i]));
         for (int l = 0; l < 3; ++l)
             UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.rec_done[l], hipEventDisableTiming));
+        UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming));
+        UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.back_done, hipEventDisableTiming));
+    }
+    if (wavefront)
+    {
+        UMX_HIP_CHECK(hipStreamCreateWithFlags(&main_stream, hipStreamNonBlocking));
+        UMX_HIP_CHECK(hipStreamCreateWithFlags(&back_stream, hipStreamNonBlocking));
+        if (const char *e = getenv("UMX_WF_ONE_STREAM")) // debugging: no concurrency between stages
+            if (atoi(e))
+            {
+                back_stream = main_stream;
+                for (int si = 0; si < 3; ++si)
+                    slot[si].stream = main_stream;
+            }
+        for (int i = 0; i < 3; ++i)
+            UMX_HIP_CHECK(hipEventCreateWithFlags(&lstm_ev[i], hipEventDisableTiming));
+        wf_sync_words = LSTM_SYNC_HEADER_WORDS + 3 * granule_count(S) * 2;
+        if (int rc = dalloc(&wf_sync, wf_sync_words))
+            return rc;
+        if (int rc = dalloc(&wf_status, 4))
+            return rc;
     }
     stream = slot[0].stream;
     {
@@ -462,7 +527,14 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
 
 int umx_hip_ctx::sync_all()
 {
-    for (int si = 0; si < 2; ++si)
+    if (wavefront)
+    {
+        if (int rc = wf_flush())
+            return rc;
+        UMX_HIP_CHECK(hipStreamSynchronize(main_stream));
+        UMX_HIP_CHECK(hipStreamSynchronize(back_stream));
+    }
+    for (int si = 0; si < nslots; ++si)
         UMX_HIP_CHECK(hipStreamSynchronize(slot[si].stream));
     return UMX_OK;
 }
@@ -518,7 +590,9 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
                       8 * S <= lstm_capacity;
     if (persistent)
     {
-        UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * lsync_words, st));
+        a.tag_base = next_tag_base();
+        // census + arrival counter every launch; the granule area only when the tag epoch wraps
+        UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (tag_epoch == 0 ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
         void *kargs[] = {&a};
         const bool precise = last_flags & UMX_FLAG_PRECISE_ACT;
         const void *fn =
@@ -561,123 +635,87 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
     return UMX_OK;
 }
 
-// ---------------------------------------------------------------- one segment
-int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags)
+// ---------------------------------------------------------------- stages of one segment
+void umx_hip_ctx::launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg)
 {
-    if (!audio_dev || n < 1 || n > N)
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = Tp;
+    g.T = T;
+    for (int i = 0; i < nact; ++i)
     {
-        set_error("infer_segment: need 1 <= n <= segment_samples and non-null audio");
-        return UMX_ERR_ARG;
-    }
-    for (int s = 0; s < 4; ++s)
-        if (!out[s])
+        const TargetBufs &b = tb[active[i]];
+        const TargetAct &c = sl.ta[active[i]];
+        GemmTarget &t = g.t[i];
+        switch (mode)
         {
-            set_error("infer_segment: null output pointer");
-            return UMX_ERR_ARG;
+        case G_FC1:
+            t.A = sl.x; t.B = b.fc1_w; t.C = c.cat;
+            t.e0 = b.bn1[0]; t.e1 = b.bn1[1]; t.e2 = b.bn1[2]; t.e3 = b.bn1[3];
+            t.q0 = b.in_scale; t.q1 = b.in_mean;
+            g.N = H; g.K = KX; g.lda = KX; g.ldc = 2 * H;
+            break;
+        case G_IH:
+            t.A = layer == 0 ? c.cat : layer == 1 ? c.la : c.lb;
+            t.B = b.ih_w[layer]; t.C = c.P; t.e0 = b.ih_b[layer];
+            g.N = 4 * H; g.K = H; g.lda = layer == 0 ? 2 * H : H; g.ldc = 4 * H;
+            break;
+        case G_FC2:
+            t.A = c.cat; t.B = b.fc2_w; t.C = c.a2;
+            t.e0 = b.bn2[0]; t.e1 = b.bn2[1]; t.e2 = b.bn2[2]; t.e3 = b.bn2[3];
+            g.N = H; g.K = 2 * H; g.lda = 2 * H; g.ldc = H;
+            break;
+        default:
+            t.A = c.a2; t.B = b.fc3_w; t.C = c.mag;
+            t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
+            t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = sl.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
+            g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0;
+            break;
         }
-    UMX_HIP_CHECK(hipSetDevice(device));
-    // pipeline slot: consecutive segments alternate slots/streams; a slot is reused two segments later
-    // (stream order protects its buffers).  Everything that touches the streaming LSTM state is ordered
-    // by events: R_l of this segment waits for R_l of the previous one.
-    const int si = (int)(nseg & 1);
-    Slot &sl = slot[si];
-    Slot &prev = slot[si ^ 1];
-    hipStream_t st = sl.stream;
-    int active[4], nact = 0;
-    for (int tg = 0; tg < 4; ++tg)
-        if (!(flags & UMX_FLAG_SKIP_TARGET(tg)))
-            active[nact++] = tg;
-    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
-    if (dbg)
-        for (int tg = 0; tg < 4; ++tg)
-            if (!sl.ta[tg].mask_dbg)
-                if (int rc = dalloc(&sl.ta[tg].mask_dbg, (size_t)T * NOUT))
-                    return rc;
-    last_flags = flags;
+    }
+    const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
+    switch (mode)
+    {
+    case G_FC1: hipLaunchKernelGGL(gemm_tn_kernel<G_FC1>, grid, block, GEMM_LDS_BYTES, st, g); break;
+    case G_IH: hipLaunchKernelGGL(gemm_tn_kernel<G_IH>, grid, block, GEMM_LDS_BYTES, st, g); break;
+    case G_FC2: hipLaunchKernelGGL(gemm_tn_kernel<G_FC2>, grid, block, GEMM_LDS_BYTES, st, g); break;
+    default: hipLaunchKernelGGL(gemm_tn_kernel<G_FC3>, grid, block, GEMM_LDS_BYTES, st, g); break;
+    }
+}
 
+// stft -> |.|, crop/stack -> fc1/bn1/tanh -> input projection of LSTM layer 0
+int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, const float *audio_dev, int n, const int *active, int nact)
+{
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_STFT], st));
     UMX_HIP_CHECK(hipMemsetAsync(sl.maxabs, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev, n, N, T, window, tw1, tw2, sl.spec,
                        sl.mix_mag, sl.x, sl.maxabs);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
-
-    auto launch_gemm = [&](int mode, int layer) {
-        GemmArgs g;
-        memset(&g, 0, sizeof g);
-        g.M = Tp;
-        g.T = T;
-        for (int i = 0; i < nact; ++i)
-        {
-            const TargetBufs &b = tb[active[i]];
-            const TargetAct &c = sl.ta[active[i]];
-            GemmTarget &t = g.t[i];
-            switch (mode)
-            {
-            case G_FC1:
-                t.A = sl.x; t.B = b.fc1_w; t.C = c.cat;
-                t.e0 = b.bn1[0]; t.e1 = b.bn1[1]; t.e2 = b.bn1[2]; t.e3 = b.bn1[3];
-                t.q0 = b.in_scale; t.q1 = b.in_mean;
-                g.N = H; g.K = KX; g.lda = KX; g.ldc = 2 * H;
-                break;
-            case G_IH:
-                t.A = layer == 0 ? c.cat : layer == 1 ? c.la : c.lb;
-                t.B = b.ih_w[layer]; t.C = c.P; t.e0 = b.ih_b[layer];
-                g.N = 4 * H; g.K = H; g.lda = layer == 0 ? 2 * H : H; g.ldc = 4 * H;
-                break;
-            case G_FC2:
-                t.A = c.cat; t.B = b.fc2_w; t.C = c.a2;
-                t.e0 = b.bn2[0]; t.e1 = b.bn2[1]; t.e2 = b.bn2[2]; t.e3 = b.bn2[3];
-                g.N = H; g.K = 2 * H; g.lda = 2 * H; g.ldc = H;
-                break;
-            default:
-                t.A = c.a2; t.B = b.fc3_w; t.C = c.mag;
-                t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
-                t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = sl.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
-                g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0;
-                break;
-            }
-        }
-        const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
-        switch (mode)
-        {
-        case G_FC1: hipLaunchKernelGGL(gemm_tn_kernel<G_FC1>, grid, block, GEMM_LDS_BYTES, st, g); break;
-        case G_IH: hipLaunchKernelGGL(gemm_tn_kernel<G_IH>, grid, block, GEMM_LDS_BYTES, st, g); break;
-        case G_FC2: hipLaunchKernelGGL(gemm_tn_kernel<G_FC2>, grid, block, GEMM_LDS_BYTES, st, g); break;
-        default: hipLaunchKernelGGL(gemm_tn_kernel<G_FC3>, grid, block, GEMM_LDS_BYTES, st, g); break;
-        }
-    };
-
     if (nact > 0)
     {
-        launch_gemm(G_FC1, 0);
-        for (int layer = 0; layer < 3; ++layer)
-        {
-            UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
-            launch_gemm(G_IH, layer);
-            if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3); if two
-                           // LSTM grids cannot be co-resident, wait for its last layer instead
-                UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[2 * 8 * S <= lstm_capacity ? layer : 2], 0));
-            UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
-            if (int rc = run_lstm_layer(sl, layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE))
-                return rc;
-            UMX_HIP_CHECK(hipEventRecord(sl.rec_done[layer], st));
-        }
-        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
-        launch_gemm(G_FC2, 0);
-        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
-        launch_gemm(G_FC3, 0);
+        launch_gemm(sl, st, G_FC1, 0, active, nact, false);
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
+        launch_gemm(sl, st, G_IH, 0, active, nact, false);
     }
     else
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
+    return UMX_OK;
+}
+
+// fc2/bn2/relu -> fc3/bn3/scale/relu/mask -> Wiener (or mix phase) -> iSTFT -> overlap-add
+int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, float *const out[4], int n, unsigned flags, const int *active,
+                            int nact)
+{
+    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
+    if (nact > 0)
     {
-        for (int k = ST_IH0; k <= ST_FC3; ++k)
-            UMX_HIP_CHECK(hipEventRecord(sl.ev[k], st));
-        for (int l = 0; l < 3; ++l)
-        {
-            if (prev.used)
-                UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[l], 0));
-            UMX_HIP_CHECK(hipEventRecord(sl.rec_done[l], st));
-        }
+        launch_gemm(sl, st, G_FC2, 0, active, nact, dbg);
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
+        launch_gemm(sl, st, G_FC3, 0, active, nact, dbg);
     }
+    else
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
     for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
         if (flags & UMX_FLAG_SKIP_TARGET(tg))
             UMX_HIP_CHECK(hipMemsetAsync(sl.ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
@@ -708,6 +746,283 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_COUNT], st));
     UMX_HIP_CHECK(hipGetLastError());
     sl.have_times = true;
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- wavefront mode (Hl = 512)
+// Segment k lives in slot k % 3.  One fused LSTM launch per queued segment advances
+//   R_0(k), R_1(k-1), R_2(k-2)
+// (lstm_wavefront_kernel); between launches the main stream runs the input projections that depend on the
+// layer outputs just produced (I_1(k), I_2(k-1)); the front of the next segment runs on its slot's stream
+// and the back of segment k-2 on the back stream, both overlapping the next LSTM launch.  umx_hip_sync
+// drains the wavefront with the partial launches {R_1, R_2} and {R_2}.
+int umx_hip_ctx::wf_launch(bool new_segment)
+{
+    (void)new_segment;
+    // jobs by LSTM stage
+    Slot *by_stage[3] = {nullptr, nullptr, nullptr};
+    for (int si = 0; si < 3; ++si)
+        if (slot[si].job_stage >= 0 && slot[si].job_stage <= 2)
+            by_stage[slot[si].job_stage] = &slot[si];
+    int mask = 0;
+    for (int l = 0; l < 3; ++l)
+        if (by_stage[l])
+            mask |= 1 << l;
+    if (!mask)
+        return UMX_OK;
+    Slot *any = by_stage[0] ? by_stage[0] : by_stage[1] ? by_stage[1] : by_stage[2];
+    const unsigned flags = any->job_flags;
+    int active[4], nact;
+    active_list(flags, active, nact);
+    hipStream_t st = main_stream;
+    if (nact > 0)
+    {
+        LstmWaveArgs a;
+        memset(&a, 0, sizeof a);
+        a.state = state;
+        a.sync = wf_sync;
+        a.status = wf_status;
+        a.S = S;
+        a.T = T;
+        a.ldp = 4 * H;
+        a.nchains = 2 * nact;
+        a.force_safe = (flags & UMX_FLAG_LSTM_FORCE_SAFE) ? 1 : 0;
+        a.prof = (flags & UMX_FLAG_LSTM_PROFILE) ? slot[0].lprof : nullptr;
+        for (int i = 0; i < 4; ++i)
+            a.tmap[i] = i < nact ? active[i] : 0;
+        for (int l = 0; l < 3; ++l)
+        {
+            LstmSet &q = a.set[l];
+            q.layer = l;
+            q.gran_off = (unsigned)(l * granule_count(S));
+            q.W = whh[l];
+            q.bhh = bhh[l];
+            if (!by_stage[l])
+                continue;
+            q.active = 1;
+            Slot &sl = *by_stage[l];
+            for (int i = 0; i < 4; ++i)
+            {
+                const TargetAct &b = sl.ta[i];
+                q.P[i] = b.P;
+                q.out[i] = l == 0 ? b.la : l == 1 ? b.lb : b.cat; // inference.cpp:118-123: layer 2 -> right half of cat
+            }
+            q.ldo = l == 2 ? 2 * H : H;
+            q.col0 = l == 2 ? H : 0;
+        }
+        if (by_stage[0])
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, by_stage[0]->front_done, 0));
+        a.tag_base = next_tag_base();
+        UMX_HIP_CHECK(hipMemsetAsync(wf_sync, 0, sizeof(unsigned) * (tag_epoch == 0 ? wf_sync_words : LSTM_SYNC_HEADER_WORDS), st));
+        void *kargs[] = {&a};
+        const bool pr = flags & UMX_FLAG_PRECISE_ACT;
+        const void *fn = nullptr;
+#define UMX_WF(M) (pr ? reinterpret_cast<const void *>(lstm_wavefront_kernel<M, true>) : reinterpret_cast<const void *>(lstm_wavefront_kernel<M, false>))
+        switch (mask)
+        {
+        case 1: fn = UMX_WF(1); break;
+        case 2: fn = UMX_WF(2); break;
+        case 3: fn = UMX_WF(3); break;
+        case 4: fn = UMX_WF(4); break;
+        case 5: fn = UMX_WF(5); break;
+        case 6: fn = UMX_WF(6); break;
+        default: fn = UMX_WF(7); break;
+        }
+#undef UMX_WF
+        for (int l = 0; l < 3; ++l)
+            if (by_stage[l])
+                UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_LSTM0 + 2 * l], st));
+        if (getenv("UMX_WF_SYNC_LAUNCH"))
+            (void)hipDeviceSynchronize();
+        UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(8 * S), dim3(LSTM_THREADS), kargs, 0, st));
+        if (getenv("UMX_WF_SYNC_LAUNCH") && atoi(getenv("UMX_WF_SYNC_LAUNCH")) > 1)
+            (void)hipDeviceSynchronize();
+        // input projections that consume the layer outputs just produced
+        for (int l = 0; l < 2; ++l)
+            if (by_stage[l])
+            {
+                UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_IH0 + 2 * (l + 1)], st));
+                launch_gemm(*by_stage[l], st, G_IH, l + 1, active, nact, false);
+            }
+        for (int l = 0; l < 3; ++l)
+            if (by_stage[l])
+                by_stage[l]->last_persistent = true;
+    }
+    else
+    {
+        if (by_stage[0])
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, by_stage[0]->front_done, 0));
+        for (int l = 0; l < 3; ++l)
+            if (by_stage[l])
+            {
+                UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_LSTM0 + 2 * l], st));
+                if (l < 2)
+                    UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_IH0 + 2 * (l + 1)], st));
+            }
+    }
+    hipEvent_t done = lstm_ev[nlaunch % 3];
+    ++nlaunch;
+    UMX_HIP_CHECK(hipEventRecord(done, st));
+    if (getenv("UMX_WF_DEBUG_STATE"))
+    {
+        (void)hipDeviceSynchronize();
+        std::vector<float> hs((size_t)4 * 12 * Hl);
+        (void)hipMemcpy(hs.data(), state, hs.size() * sizeof(float), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[wf] launch %lld mask %d state checksums (target 1):", nlaunch, mask);
+        for (int l = 0; l < 3; ++l)
+            for (int d = 0; d < 2; ++d)
+                for (int hc = 0; hc < 2; ++hc)
+                {
+                    double acc = 0;
+                    const float *q = hs.data() + state_off(1, l, d, hc, Hl);
+                    for (int i = 0; i < Hl; ++i)
+                        acc += (double)q[i] * (i + 1);
+                    fprintf(stderr, " L%d%c%c=%.9g", l, d ? 'b' : 'f', hc ? 'c' : 'h', acc);
+                }
+        fprintf(stderr, "\n");
+    }
+    // the segment that just finished layer 2 goes to the back stream
+    if (by_stage[2])
+    {
+        Slot &sl = *by_stage[2];
+        UMX_HIP_CHECK(hipStreamWaitEvent(back_stream, done, 0));
+        int act2[4], n2;
+        active_list(sl.job_flags, act2, n2);
+        if (int rc = stage_back(sl, back_stream, sl.job_out, sl.job_n, sl.job_flags, act2, n2))
+            return rc;
+        UMX_HIP_CHECK(hipEventRecord(sl.back_done, back_stream));
+        sl.job_stage = -1;
+    }
+    if (by_stage[1])
+        by_stage[1]->job_stage = 2;
+    if (by_stage[0])
+        by_stage[0]->job_stage = 1;
+    UMX_HIP_CHECK(hipGetLastError());
+    return UMX_OK;
+}
+
+int umx_hip_ctx::wf_flush()
+{
+    for (int guard = 0; guard < 4; ++guard)
+    {
+        bool pending = false;
+        for (int si = 0; si < 3; ++si)
+            pending = pending || slot[si].job_stage >= 0;
+        if (!pending)
+            return UMX_OK;
+        if (int rc = wf_launch(false))
+            return rc;
+    }
+    return UMX_OK;
+}
+
+int umx_hip_ctx::wf_enqueue(const float *audio_dev, int n, float *const out[4], unsigned flags)
+{
+    // a change of the target set / protocol flags cannot share a fused launch: drain first
+    const unsigned key_mask = 0xF00u | UMX_FLAG_LSTM_FORCE_SAFE | UMX_FLAG_PRECISE_ACT;
+    for (int si = 0; si < 3; ++si)
+        if (slot[si].job_stage >= 0 && ((slot[si].job_flags ^ flags) & key_mask))
+        {
+            if (int rc = wf_flush())
+                return rc;
+            break;
+        }
+    const int si = (int)(nseg % 3);
+    Slot &sl = slot[si];
+    if (sl.job_stage >= 0) // cannot happen: a slot is drained two launches after it was filled
+    {
+        set_error("wavefront slot still busy");
+        return UMX_ERR_ARG;
+    }
+    int active[4], nact;
+    active_list(flags, active, nact);
+    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
+    if (dbg)
+        for (int tg = 0; tg < 4; ++tg)
+            if (!sl.ta[tg].mask_dbg)
+                if (int rc = dalloc(&sl.ta[tg].mask_dbg, (size_t)T * NOUT))
+                    return rc;
+    last_flags = flags;
+    // the slot's buffers are free once the back stage of the segment that used them last has finished
+    if (sl.used)
+        UMX_HIP_CHECK(hipStreamWaitEvent(sl.stream, sl.back_done, 0));
+    if (int rc = stage_front(sl, sl.stream, audio_dev, n, active, nact))
+        return rc;
+    UMX_HIP_CHECK(hipEventRecord(sl.front_done, sl.stream));
+    for (int s = 0; s < 4; ++s)
+        sl.job_out[s] = out[s];
+    sl.job_n = n;
+    sl.job_flags = flags;
+    sl.job_stage = 0;
+    sl.used = true;
+    cur = si;
+    ++nseg;
+    return wf_launch(true);
+}
+
+// ---------------------------------------------------------------- one segment
+int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags)
+{
+    if (!audio_dev || n < 1 || n > N)
+    {
+        set_error("infer_segment: need 1 <= n <= segment_samples and non-null audio");
+        return UMX_ERR_ARG;
+    }
+    for (int s = 0; s < 4; ++s)
+        if (!out[s])
+        {
+            set_error("infer_segment: null output pointer");
+            return UMX_ERR_ARG;
+        }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    if (wavefront && !(flags & UMX_FLAG_LSTM_STEPWISE) && persistent_ok && 8 * S <= lstm_capacity)
+    {
+        last_was_wavefront = true;
+        return wf_enqueue(audio_dev, n, out, flags);
+    }
+    last_was_wavefront = false;
+    if (wavefront) // per-layer path requested while wavefront jobs may be in flight: drain them first
+    {
+        if (int rc = sync_all())
+            return rc;
+    }
+    // "slots" mode: consecutive segments alternate between two slots/streams; a slot is reused two
+    // segments later (stream order protects its buffers).  Everything that touches the streaming LSTM
+    // state is ordered by events: R_l of this segment waits for R_l of the previous one.
+    const int si = (int)(nseg & 1);
+    Slot &sl = slot[si];
+    Slot &prev = slot[si ^ 1];
+    hipStream_t st = sl.stream;
+    int active[4], nact;
+    active_list(flags, active, nact);
+    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
+    if (dbg)
+        for (int tg = 0; tg < 4; ++tg)
+            if (!sl.ta[tg].mask_dbg)
+                if (int rc = dalloc(&sl.ta[tg].mask_dbg, (size_t)T * NOUT))
+                    return rc;
+    last_flags = flags;
+    if (int rc = stage_front(sl, st, audio_dev, n, active, nact))
+        return rc;
+    for (int layer = 0; layer < 3; ++layer)
+    {
+        if (layer > 0)
+        {
+            UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
+            if (nact > 0)
+                launch_gemm(sl, st, G_IH, layer, active, nact, false);
+        }
+        if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3); if two
+                       // LSTM grids cannot be co-resident, wait for its last layer instead
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[2 * 8 * S <= lstm_capacity ? layer : 2], 0));
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
+        if (nact > 0)
+            if (int rc = run_lstm_layer(sl, layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE))
+                return rc;
+        UMX_HIP_CHECK(hipEventRecord(sl.rec_done[layer], st));
+    }
+    if (int rc = stage_back(sl, st, out, n, flags, active, nact))
+        return rc;
     sl.used = true;
     cur = si;
     ++nseg;
@@ -744,14 +1059,22 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
     if (!ctx)
         return;
     (void)hipSetDevice(ctx->device);
-    for (int si = 0; si < 2; ++si)
-        if (ctx->slot[si].stream)
-            (void)hipStreamSynchronize(ctx->slot[si].stream);
+    (void)hipDeviceSynchronize();
     for (void *p : ctx->allocs)
         (void)hipFree(p);
-    for (int si = 0; si < 2; ++si)
+    for (hipStream_t q : {ctx->main_stream, ctx->back_stream})
+        if (q)
+            (void)hipStreamDestroy(q);
+    for (int i = 0; i < 3; ++i)
+        if (ctx->lstm_ev[i])
+            (void)hipEventDestroy(ctx->lstm_ev[i]);
+    for (int si = 0; si < 3; ++si)
     {
         Slot &sl = ctx->slot[si];
+        if (sl.front_done)
+            (void)hipEventDestroy(sl.front_done);
+        if (sl.back_done)
+            (void)hipEventDestroy(sl.back_done);
         for (int i = 0; i <= ST_COUNT; ++i)
             if (sl.ev[i])
                 (void)hipEventDestroy(sl.ev[i]);
@@ -780,7 +1103,7 @@ int umx_hip_stream_reset(umx_hip_ctx *ctx)
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
-    ctx->slot[0].used = ctx->slot[1].used = false; // a new track: no cross-segment dependency to wait for
+    ctx->slot[0].used = ctx->slot[1].used = ctx->slot[2].used = false; // a new track: no cross-segment dependency to wait for
     return UMX_OK;
 }
 
@@ -811,7 +1134,7 @@ int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src)
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
-    ctx->slot[0].used = ctx->slot[1].used = false;
+    ctx->slot[0].used = ctx->slot[1].used = ctx->slot[2].used = false;
     return UMX_OK;
 }
 
@@ -829,10 +1152,13 @@ int umx_hip_sync(umx_hip_ctx *ctx)
         return UMX_ERR_ARG;
     if (int rc = ctx->sync_all())
         return rc;
-    for (int si = 0; si < 2; ++si)
+    for (int si = 0; si < ctx->nslots + 1; ++si)
     {
+        unsigned *dev_status = si < ctx->nslots ? ctx->slot[si].status : ctx->wf_status;
+        if (!dev_status)
+            continue;
         unsigned st = 0;
-        hipError_t e = hipMemcpy(&st, ctx->slot[si].status, sizeof st, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(&st, dev_status, sizeof st, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
         {
             ctx->set_error(hipGetErrorString(e));
@@ -842,9 +1168,9 @@ int umx_hip_sync(umx_hip_ctx *ctx)
         {
             ctx->set_error(st == 0x80000000u
                                ? std::string("persistent LSTM kernel: grid barrier timed out (grid not co-resident)")
-                               : "persistent LSTM kernel timed out waiting for a hidden-state granule at step " +
-                                     std::to_string(st - 1));
-            (void)hipMemset(ctx->slot[si].status, 0, sizeof(unsigned));
+                               : "persistent LSTM kernel timed out waiting for a hidden-state granule (code " +
+                                     std::to_string(st) + ")");
+            (void)hipMemset(dev_status, 0, sizeof(unsigned));
             ctx->persistent_ok = false;
             return UMX_ERR_TIMEOUT;
         }
@@ -863,7 +1189,7 @@ int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, floa
     // the staging buffers are shared, so the host-pointer form is strictly one segment at a time
     if (int rc = ctx->sync_all())
         return rc;
-    hipStream_t st = ctx->slot[ctx->nseg & 1].stream;
+    hipStream_t st = ctx->slot[ctx->wavefront ? ctx->nseg % 3 : ctx->nseg & 1].stream;
     hipError_t e = hipMemcpyAsync(ctx->audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st);
     if (e != hipSuccess)
     {
@@ -873,19 +1199,24 @@ int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, floa
     int rc = ctx->infer_device(ctx->audio_in, n, ctx->out_dev, flags);
     if (rc)
         return rc;
+    // results are complete only after the pipeline has drained (wavefront mode finishes the segment's
+    // layers 1 and 2 and its back stage during the flush)
+    rc = umx_hip_sync(ctx);
+    if (rc)
+        return rc;
     for (int s = 0; s < 4; ++s)
     {
-        e = hipMemcpyAsync(out_host[s], ctx->out_dev[s], sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, st);
+        e = hipMemcpy(out_host[s], ctx->out_dev[s], sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
         {
             ctx->set_error(hipGetErrorString(e));
             return UMX_ERR_HIP;
         }
     }
-    return umx_hip_sync(ctx);
+    return UMX_OK;
 }
 
-void *umx_hip_stream_handle(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->slot[ctx->nseg & 1].stream : nullptr; }
+void *umx_hip_stream_handle(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->slot[ctx->cur].stream : nullptr; }
 int umx_hip_nb_frames(const umx_hip_ctx *ctx) { return ctx ? ctx->T : 0; }
 int umx_hip_segment_samples(const umx_hip_ctx *ctx) { return ctx ? ctx->N : 0; }
 int umx_hip_hidden(const umx_hip_ctx *ctx) { return ctx ? ctx->H : 0; }
@@ -894,9 +1225,17 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
 {
     if (!ctx || !what || target < 0 || target > 3)
         return -1;
-    const std::string w = what;
+    std::string w = what;
     const int T = ctx->T, H = ctx->H;
-    const Slot &sl = ctx->slot[ctx->cur];
+    int which = ctx->cur;
+    if (w.size() > 2 && w[w.size() - 2] == '@') // "name@s": pipeline slot s instead of the most recent one
+    {
+        which = w.back() - '0';
+        w = w.substr(0, w.size() - 2);
+        if (which < 0 || which >= ctx->nslots)
+            return -1;
+    }
+    const Slot &sl = ctx->slot[which];
     const void *src = nullptr;
     size_t nfl = 0, src_ld = 0, rows = 0, cols = 0; // strided copy when src_ld != cols
     if (w == "spec") { src = sl.spec; nfl = (size_t)2 * 2 * T * NBINS; }
@@ -904,6 +1243,9 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
     else if (w == "x") { src = sl.x; nfl = (size_t)T * KX; }
     else if (w == "fc1") { src = sl.ta[target].cat; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
     else if (w == "lstm") { src = sl.ta[target].cat + H; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
+    else if (w == "lstm_l0") { src = sl.ta[target].la; nfl = (size_t)T * H; }
+    else if (w == "lstm_l1") { src = sl.ta[target].lb; nfl = (size_t)T * H; }
+    else if (w == "proj") { src = sl.ta[target].P; nfl = (size_t)T * 4 * H; }
     else if (w == "mask") { src = sl.ta[target].mask_dbg; nfl = (size_t)T * NOUT; }
     else if (w == "target_mag") { src = sl.ta[target].mag; nfl = (size_t)2 * T * NBINS; }
     else if (w == "y") { src = sl.y + (size_t)target * 2 * T * NBINS; nfl = (size_t)2 * 2 * T * NBINS; }
@@ -972,8 +1314,8 @@ int umx_hip_lstm_mode(umx_hip_ctx *ctx)
     if (!ctx || !ctx->slot[ctx->cur].last_persistent)
         return 0;
     unsigned st[2] = {0, 0};
-    if (ctx->sync_all() != UMX_OK ||
-        hipMemcpy(st, ctx->slot[ctx->cur].status, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
+    const unsigned *src = ctx->last_was_wavefront ? ctx->wf_status : ctx->slot[ctx->cur].status;
+    if (ctx->sync_all() != UMX_OK || hipMemcpy(st, src, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
         return -1;
     return st[1] ? 2 : 1;
 }
@@ -983,7 +1325,7 @@ int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48)
     if (!ctx || !out48)
         return UMX_ERR_ARG;
     if (ctx->sync_all() != UMX_OK ||
-        hipMemcpy(out48, ctx->slot[ctx->cur].lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(out48, ctx->slot[ctx->last_was_wavefront ? 0 : ctx->cur].lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
         return UMX_ERR_HIP;
     return UMX_OK;
 }

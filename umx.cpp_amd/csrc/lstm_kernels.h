@@ -56,6 +56,8 @@ struct LstmArgs
     int Hl, S, T, ldp, ldo, col0, layer, nchains;
     int tmap[4];      // chain>>1 -> target (targets can be skipped: BASELINE config 1)
     int force_safe;   // 1 = never use the intra-XCD protocol (testing)
+    unsigned tag_base; // granule tag of step s = tag_base + s + 1: unique per launch, so a granule line left in
+                       // some L2 by an earlier launch can never pass for this launch's data
 };
 
 constexpr int LSTM_SYNC_HEADER_WORDS = 32; // census[8], arrivals, pad -> granules start 128-byte aligned
@@ -132,7 +134,7 @@ __device__ __forceinline__ int dpp_ror_direction()
     return (((src - lane) & 15) == 1) ? 1 : -1;
 }
 
-__device__ __forceinline__ size_t state_off(int target, int layer, int dir, int hc, int Hl)
+__host__ __device__ __forceinline__ size_t state_off(int target, int layer, int dir, int hc, int Hl)
 {
     return ((((size_t)target * 3 + layer) * 2 + dir) * 2 + hc) * Hl;
 }
@@ -381,7 +383,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 // wait for h_{step-1}: tag == step, slot (step-1)&1.  A granule keeps its tag until it is
                 // overwritten two steps later, so every lane reloads until one poll shows all tags.
                 gu64 *g = gran + granule_index((step - 1) & 1, chain, w * KPW + (l < KPW ? l : 0), a.S);
-                const unsigned want = (unsigned)step;
+                const unsigned want = a.tag_base + (unsigned)step;
                 // The gate wave needs ~600 cycles before anything can change: sleep through that, then keep
                 // three polls in flight so the poll period is a third of the L2 round trip (the step time is
                 // a maximum over ~2000 polling waves: the quantisation is paid almost in full every step).
@@ -480,7 +482,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             if ((l & 3) == 0)
             {
                 const unsigned long long gv =
-                    ((unsigned long long)(unsigned)(step + 1) << 32) | (unsigned long long)__float_as_uint(h);
+                    ((unsigned long long)(a.tag_base + (unsigned)(step + 1)) << 32) | (unsigned long long)__float_as_uint(h);
                 granule_store<FAST>(gran + granule_index(step & 1, chain, unit, a.S), gv);
                 a.out[target][(size_t)t * a.ldo + a.col0 + dir * Hl + unit] = h;
                 hlast = h;
