@@ -41,6 +41,9 @@ namespace umx
 {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+#ifndef LSTM_DOT_PK
+#define LSTM_DOT_PK 1 // 1: rotations (2m, 2m+1) feed one v_pk_fma_f32 (even-n / odd-n partial sums); 0: 64 v_fmac_f32
+#endif
 
 struct LstmArgs
 {
@@ -167,6 +170,17 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
         float pr[4];
         for (int r = 0; r < 4; ++r)
         {
+#if LSTM_DOT_PK
+            float acc_e = 0.f, acc_o = 0.f; // even / odd rotations: the two halves of v_pk_fma_f32
+            for (int n = 0; n < 16; n += 2)
+            {
+                const int ke = 64 * w + 16 * r + ((u + rdir * n) & 15);
+                const int ko = 64 * w + 16 * r + ((u + rdir * (n + 1)) & 15);
+                acc_e = fmaf(Wc[(size_t)ke * 64], hs[ke], acc_e);
+                acc_o = fmaf(Wc[(size_t)ko * 64], hs[ko], acc_o);
+            }
+            pr[r] = acc_e + acc_o;
+#else
             float acc = 0.f;
             for (int n = 0; n < 16; ++n)
             {
@@ -174,6 +188,7 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
                 acc = fmaf(Wc[(size_t)k * 64], hs[k], acc);
             }
             pr[r] = acc;
+#endif
         }
         partial = (pr[0] + pr[2]) + (pr[1] + pr[3]);
     }
@@ -264,22 +279,78 @@ __device__ __forceinline__ unsigned long long granule_load(gu64 *p)
 }
 
 // KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64, even.
+#if LSTM_DOT_PK
+// register-resident W_hh slice of one lane: rotation pairs (2m, 2m+1) are adjacent registers
+struct WSlice
+{
+    float2v v[8][4];
+    __device__ __forceinline__ void set(int n, const float4 &x)
+    {
+        v[n >> 1][0][n & 1] = x.x;
+        v[n >> 1][1][n & 1] = x.y;
+        v[n >> 1][2][n & 1] = x.z;
+        v[n >> 1][3][n & 1] = x.w;
+    }
+};
+// acc2[cc] += (W[2M][cc], W[2M+1][cc]) * (h ror 2M, h ror 2M+1) for M = 0 .. 7; the caller adds .x + .y
+template <int M> struct DotDppPk
+{
+    static __device__ __forceinline__ void run(const WSlice &W, int hbits, float2v (&acc2)[4])
+    {
+        DotDppPk<M - 1>::run(W, hbits, acc2);
+        float2v hr;
+        hr.x = __int_as_float(dpp_row_ror<2 * M>(hbits));
+        hr.y = __int_as_float(dpp_row_ror<2 * M + 1>(hbits));
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            acc2[cc] = __builtin_elementwise_fma(W.v[M][cc], hr, acc2[cc]);
+    }
+};
+template <> struct DotDppPk<-1>
+{
+    static __device__ __forceinline__ void run(const WSlice &, int, float2v (&)[4]) {}
+};
+template <int N> struct DotDpp
+{
+    static_assert(N == 15, "full 16-rotation dot only");
+    static __device__ __forceinline__ void run(const WSlice &W, int hbits, float (&acc)[4])
+    {
+        float2v acc2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        DotDppPk<7>::run(W, hbits, acc2);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            acc[cc] = acc2[cc].x + acc2[cc].y;
+    }
+};
+#else
+struct WSlice
+{
+    float v[16][4];
+    __device__ __forceinline__ void set(int n, const float4 &x)
+    {
+        v[n][0] = x.x;
+        v[n][1] = x.y;
+        v[n][2] = x.z;
+        v[n][3] = x.w;
+    }
+};
 template <int N> struct DotDpp
 {
     // acc[cc] += W[N][cc] * h(rotated by N lanes inside the row), for N = 15 .. 0 recursively
-    static __device__ __forceinline__ void run(const float (&W)[16][4], int hbits, float (&acc)[4])
+    static __device__ __forceinline__ void run(const WSlice &W, int hbits, float (&acc)[4])
     {
         DotDpp<N - 1>::run(W, hbits, acc);
         const float hr = __int_as_float(dpp_row_ror<N>(hbits));
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
-            acc[cc] = fmaf(W[N][cc], hr, acc[cc]);
+            acc[cc] = fmaf(W.v[N][cc], hr, acc[cc]);
     }
 };
 template <> struct DotDpp<-1>
 {
-    static __device__ __forceinline__ void run(const float (&)[16][4], int, float (&)[4]) {}
+    static __device__ __forceinline__ void run(const WSlice &, int, float (&)[4]) {}
 };
+#endif
 template <int N> struct KidxDpp
 {
     static __device__ __forceinline__ void run(int lane_k, int (&kidx)[16])
@@ -312,7 +383,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     //   (k even, k odd) feed v_pk_fma_f32 with an SGPR pair from v_readlane.
     constexpr bool DPP = (KPW == 64);
     float2v W[KPW / 2]; // dead in the DPP instantiation
-    float Wd[16][4];    // dead in the readlane instantiations
+    WSlice Wd;          // dead in the readlane instantiations
     if (w >= 8)
     {
         // gate wave: no weights
@@ -326,10 +397,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         for (int n = 0; n < 16; ++n)
         {
             const float4 v = *reinterpret_cast<const float4 *>(Wb + (size_t)kidx[n] * 64);
-            Wd[n][0] = v.x;
-            Wd[n][1] = v.y;
-            Wd[n][2] = v.z;
-            Wd[n][3] = v.w;
+            Wd.set(n, v);
         }
     }
     else

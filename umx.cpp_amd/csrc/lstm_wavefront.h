@@ -101,7 +101,7 @@ constexpr int wf_prev(int mask, int m)
 // everything one wave keeps across steps
 struct WfWave
 {
-    float Wd[3][16][4];
+    WSlice Wd[3];
     float hval[3];
     unsigned long long pend[3]; // granule loads issued one task ahead
     float c, bh, hlast, p, p_old; // gate duty: cell state, b_hh, last h, P of this step / of the previous step
@@ -290,7 +290,7 @@ __device__ __forceinline__ void lstm_wavefront_body(const LstmWaveArgs &a, int c
 
     // ---- register-resident W_hh slices of the active sets (DPP layout, see lstm_kernels.h)
     WfWave ws;
-    float(&Wd)[3][16][4] = ws.Wd;
+    WSlice(&Wd)[3] = ws.Wd;
     {
         int kidx[16];
         KidxDpp<15>::run(w * KPW + l, kidx);
@@ -303,10 +303,7 @@ __device__ __forceinline__ void lstm_wavefront_body(const LstmWaveArgs &a, int c
                 for (int n = 0; n < 16; ++n)
                 {
                     const float4 v = *reinterpret_cast<const float4 *>(Wb + (size_t)kidx[n] * 64);
-                    Wd[m][n][0] = v.x;
-                    Wd[m][n][1] = v.y;
-                    Wd[m][n][2] = v.z;
-                    Wd[m][n][3] = v.w;
+                    Wd[m].set(n, v);
                 }
             }
     }
