@@ -56,6 +56,9 @@ __device__ __forceinline__ float4 scale_shift(float4 a, float4 sc, float4 mn)
     return make_float4(a.x * sc.x + mn.x, a.y * sc.y + mn.y, a.z * sc.z + mn.z, a.w * sc.w + mn.w);
 }
 
+// Register budget of the two-slot pipeline (engine.hip): two GEMM blocks (136 VGPRs allocated) must fit a CU
+// beside two 8-wave LSTM workgroups of the other slot (104 each): 2 x 104 + 2 x 136 = 480 <= 512 per SIMD lane.
+// An LSTM kernel above 120 VGPRs halves the overlapped GEMMs' occupancy (measured: 0.9 -> 2.2 ms).
 template <int MODE> __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -42,7 +42,8 @@ namespace umx
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 #ifndef LSTM_DOT_PK
-#define LSTM_DOT_PK 1 // 1: rotations (2m, 2m+1) feed one v_pk_fma_f32 (even-n / odd-n partial sums); 0: 64 v_fmac_f32
+#define LSTM_DOT_PK 1 // 1: rotations (2m, 2m+1) feed one v_pk_fma_f32 (even-n / odd-n partial sums); 0: 64 v_fmac_f32 +
+                      // 15 DPP movs; 2: 64 v_fmac_f32_dpp (rotation folded into the FMA's src0, same order as 0)
 #endif
 
 struct LstmArgs
@@ -170,7 +171,7 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
         float pr[4];
         for (int r = 0; r < 4; ++r)
         {
-#if LSTM_DOT_PK
+#if LSTM_DOT_PK == 1
             float acc_e = 0.f, acc_o = 0.f; // even / odd rotations: the two halves of v_pk_fma_f32
             for (int n = 0; n < 16; n += 2)
             {
@@ -253,6 +254,13 @@ constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then 
 #ifndef LSTM_POLLS_IN_FLIGHT
 #define LSTM_POLLS_IN_FLIGHT 1 // measured best once two LSTM grids share the chip (2: -3 %, 3: -5 %)
 #endif
+#ifndef LSTM_PROF_WAVE
+#define LSTM_PROF_WAVE 1 // the dot wave the in-kernel profiler reports beside the gate wave
+#endif
+#ifndef LSTM_GATE_POLL_DELAY
+#define LSTM_GATE_POLL_DELAY 0 // x64 cycles the gate wave waits after publishing before its own first poll
+                               // (measured 0..4: 0 is best, its first poll already succeeds)
+#endif
 #ifndef LSTM_POLL_DELAY
 #define LSTM_POLL_DELAY 8 // x64 shader cycles a dot wave sleeps after the barrier before its first poll
 #endif
@@ -279,7 +287,7 @@ __device__ __forceinline__ unsigned long long granule_load(gu64 *p)
 }
 
 // KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64, even.
-#if LSTM_DOT_PK
+#if LSTM_DOT_PK == 1
 // register-resident W_hh slice of one lane: rotation pairs (2m, 2m+1) are adjacent registers
 struct WSlice
 {
@@ -340,6 +348,17 @@ template <int N> struct DotDpp
     static __device__ __forceinline__ void run(const WSlice &W, int hbits, float (&acc)[4])
     {
         DotDpp<N - 1>::run(W, hbits, acc);
+#if LSTM_DOT_PK == 2
+        if constexpr (N > 0)
+        {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf"
+                             : "+v"(acc[cc])
+                             : "v"(hbits), "v"(W.v[N][cc]), "n"(N));
+            return;
+        }
+#endif
         const float hr = __int_as_float(dpp_row_ror<N>(hbits));
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
@@ -366,11 +385,13 @@ template <> struct KidxDpp<-1>
 
 template <int KPW, bool FAST, bool PRECISE>
 __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chain, int slice, float (*part)[8][64],
-                                                      int *abort_flag)
+                                                      float (*pbuf)[64], int *abort_flag)
 {
     const int target = a.tmap[chain >> 1], dir = chain & 1;
     const int wchain = target * 2 + dir;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    // w (and with it every role test) is wave-uniform: keep it in an SGPR so role branches are scalar and
+    // the profiler's counters cost no VGPRs
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
     constexpr int Hl = KPW * 8;
     const int T = a.T;
 
@@ -430,9 +451,29 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
 
     gu64 *gran = (gu64 *)(a.sync + LSTM_SYNC_HEADER_WORDS);
     gu32 *status = (gu32 *)a.status;
-    const float *Pp = a.P[target] + ((size_t)dir * a.S + slice) * 64 + l;
+    // everything indexed by the runtime `target` is resolved once, outside the step loop (a dynamic index
+    // into the by-value argument struct is a memory load, and the granule store's compiler barrier would
+    // otherwise force it back into every step, right on the gate wave's critical path)
+    const float *const Pp = a.P[target] + ((size_t)dir * a.S + slice) * 64 + l;
+    float *const outp = a.out[target] + a.col0 + dir * Hl + unit;
+    const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo;
+    const unsigned tag_base = a.tag_base;
+    const int S = a.S;
     float hlast = 0.f;
-    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && l == 0 && (w == gw || w == 1);
+    // W_ih x + b_ih rows come from HBM (~750 cycles) and vmcnt retires in order, so a load issued by the gate
+    // wave would hold its next poll -- the chain's critical path -- for the HBM latency.  Wave 7 (which
+    // idles at the barrier anyway) fetches row t+2 right before barrier t and parks row t+1 in LDS; the gate
+    // wave reads its row from LDS together with the partial sums.  Four slots: row t+1 is written while
+    // row t-1 may still be read.
+    const bool p_wave = (w == 7);
+    float preg = 0.f;
+    if (p_wave)
+    {
+        pbuf[0][l] = Pp[(size_t)(dir == 0 ? 0 : T - 1) * ldp];
+        if (T > 1)
+            preg = Pp[(size_t)(dir == 0 ? 1 : T - 2) * ldp];
+    }
+    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == gw || w == LSTM_PROF_WAVE); // wave-uniform
     unsigned long long pc[5] = {0, 0, 0, 0, 0};
 
     for (int step = 0; step < T; ++step)
@@ -441,22 +482,24 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (prof)
             c0 = clock64();
-        float p = 0.f;
-        if (gate_wave)
-            p = Pp[(size_t)t * a.ldp]; // issued a whole step ahead of its use
         if (dot_wave)
         {
             if (step > 0)
             {
                 // wait for h_{step-1}: tag == step, slot (step-1)&1.  A granule keeps its tag until it is
                 // overwritten two steps later, so every lane reloads until one poll shows all tags.
-                gu64 *g = gran + granule_index((step - 1) & 1, chain, w * KPW + (l < KPW ? l : 0), a.S);
-                const unsigned want = a.tag_base + (unsigned)step;
+                gu64 *g = gran + granule_index((step - 1) & 1, chain, w * KPW + (l < KPW ? l : 0), S);
+                const unsigned want = tag_base + (unsigned)step;
                 // The gate wave needs ~600 cycles before anything can change: sleep through that, then keep
                 // three polls in flight so the poll period is a third of the L2 round trip (the step time is
                 // a maximum over ~2000 polling waves: the quantisation is paid almost in full every step).
-                if (FAST && !gate_wave)
-                    __builtin_amdgcn_s_sleep(LSTM_POLL_DELAY);
+                if (FAST)
+                {
+                    if (!gate_wave)
+                        __builtin_amdgcn_s_sleep(LSTM_POLL_DELAY);
+                    else if (LSTM_GATE_POLL_DELAY > 0)
+                        __builtin_amdgcn_s_sleep(LSTM_GATE_POLL_DELAY);
+                }
                 unsigned long long x = granule_load(g), xb = 0, xc = 0;
                 if (LSTM_POLLS_IN_FLIGHT >= 2)
                     xb = granule_load(g);
@@ -533,6 +576,13 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 (*(part + (step & 1)))[w][l] = acc.x + acc.y;
             }
         }
+        if (p_wave)
+        {
+            pbuf[(step + 1) & 3][l] = preg; // row step+1, loaded one step ago
+            asm volatile("" ::: "memory");
+            if (step + 2 < T)
+                preg = Pp[(size_t)(dir == 0 ? step + 2 : T - 3 - step) * ldp];
+        }
         if (prof)
             c2 = clock64();
         __syncthreads();
@@ -544,15 +594,15 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         {
             float(*pq)[64] = *(part + (step & 1));
             const float s = ((pq[0][l] + pq[1][l]) + (pq[2][l] + pq[3][l])) + ((pq[4][l] + pq[5][l]) + (pq[6][l] + pq[7][l]));
-            const float pre = (p + s) + bh;
+            const float pre = (pbuf[step & 3][l] + s) + bh;
             float h;
             lstm_cell<PRECISE>(pre, l, c, h);
             if ((l & 3) == 0)
             {
                 const unsigned long long gv =
-                    ((unsigned long long)(a.tag_base + (unsigned)(step + 1)) << 32) | (unsigned long long)__float_as_uint(h);
-                granule_store<FAST>(gran + granule_index(step & 1, chain, unit, a.S), gv);
-                a.out[target][(size_t)t * a.ldo + a.col0 + dir * Hl + unit] = h;
+                    ((unsigned long long)(tag_base + (unsigned)(step + 1)) << 32) | (unsigned long long)__float_as_uint(h);
+                granule_store<FAST>(gran + granule_index(step & 1, chain, unit, S), gv);
+                outp[(size_t)t * ldo] = h;
                 hlast = h;
             }
         }
@@ -571,15 +621,17 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         a.state[state_off(target, a.layer, dir, 0, Hl) + unit] = hlast;
         a.state[state_off(target, a.layer, dir, 1, Hl) + unit] = c;
     }
-    if (prof)
+    if (prof && l == 0)
         for (int i = 0; i < 5; ++i)
             a.prof[(a.layer * 2 + (w == gw ? 0 : 1)) * 8 + i] = pc[i];
 }
 
 // grid = 8*S workgroups (1-D), cooperative launch.  Roles come from the census (see file header).
+// Must stay <= 120 VGPRs: see gemm_kernels.h (register budget of the two-slot pipeline)
 template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_THREADS) void lstm_persistent_kernel(LstmArgs a)
 {
     __shared__ float part[2][8][64];
+    __shared__ float pbuf[4][64]; // W_ih x + b_ih rows of steps t .. t+1 (see lstm_persistent_body)
     __shared__ int s_ctl[4]; // chain, slice, fast, abort
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, S = a.S;
@@ -624,9 +676,9 @@ template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_TH
     if (s_ctl[3] || chain >= a.nchains) // aborted, or an XCD / block range with no chain to run
         return;
     if (s_ctl[2])
-        lstm_persistent_body<KPW, true, PRECISE>(a, chain, slice, part, &s_ctl[3]);
+        lstm_persistent_body<KPW, true, PRECISE>(a, chain, slice, part, pbuf, &s_ctl[3]);
     else
-        lstm_persistent_body<KPW, false, PRECISE>(a, chain, slice, part, &s_ctl[3]);
+        lstm_persistent_body<KPW, false, PRECISE>(a, chain, slice, part, pbuf, &s_ctl[3]);
 }
 
 } // namespace umx
