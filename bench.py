@@ -221,12 +221,14 @@ def main():
         print(json.dumps(line), flush=True)
         if args.lstm_profile:
             pr = eng.lstm_profile()
-            if eng.lstm_mode() >= 1 and H == 1024 and not args.stepwise_lstm:
-                for wi, wn in ((0, "wave 0 (gate duty set 0)"), (1, "wave 3")):
-                    c = prof_pipelined.reshape(6, 8)[wi]
-                    n = max(int(c[4]), 1)
-                    print(f"# wavefront kernel {wn}: cycles/task poll {c[0] / n:.0f} dot {c[1] * 3 / (2 if wi == 0 else 3) / n:.0f} "
-                          f"gate_wait {c[2] * 3 / n:.0f} gates+dot {c[3] * 3 / n:.0f} (tasks {int(c[4])})", file=sys.stderr)
+            if prof_pipelined is not None and not args.serial:
+                pp = prof_pipelined.reshape(-1)[:48].reshape(3, 2, 8)
+                for layer in range(3):
+                    for w in range(2):
+                        c = pp[layer, w]
+                        n = max(int(c[4]), 1)
+                        print(f"# pipelined lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
+                              f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} (steps {int(c[4])})", file=sys.stderr)
             for layer in range(3):
                 for w in range(2):
                     c = pr[layer, w]

@@ -257,6 +257,9 @@ constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then 
 #ifndef LSTM_PROF_WAVE
 #define LSTM_PROF_WAVE 1 // the dot wave the in-kernel profiler reports beside the gate wave
 #endif
+#ifndef LSTM_GATE_PRIO
+#define LSTM_GATE_PRIO 1 // s_setprio of the gate wave during its serial gate phase (measured: -1.5 % per segment pipelined)
+#endif
 #ifndef LSTM_GATE_POLL_DELAY
 #define LSTM_GATE_POLL_DELAY 0 // x64 cycles the gate wave waits after publishing before its own first poll
                                // (measured 0..4: 0 is best, its first poll already succeeds)
@@ -592,6 +595,9 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             c3 = clock64();
         if (gate_wave)
         {
+#if LSTM_GATE_PRIO
+            __builtin_amdgcn_s_setprio(LSTM_GATE_PRIO); // the serial gate phase wins issue arbitration against dot waves
+#endif
             float(*pq)[64] = *(part + (step & 1));
             const float s = ((pq[0][l] + pq[1][l]) + (pq[2][l] + pq[3][l])) + ((pq[4][l] + pq[5][l]) + (pq[6][l] + pq[7][l]));
             const float pre = (pbuf[step & 3][l] + s) + bh;
@@ -605,6 +611,9 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 outp[(size_t)t * ldo] = h;
                 hlast = h;
             }
+#if LSTM_GATE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         if (prof)
         {
