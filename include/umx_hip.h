@@ -92,6 +92,18 @@ int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n
 int umx_hip_sync(umx_hip_ctx *ctx); /* also surfaces a persistent-kernel timeout as UMX_ERR_TIMEOUT */
 void *umx_hip_stream_handle(umx_hip_ctx *ctx); /* the hipStream_t all work is queued on */
 
+/* One segment phase by phase: front (STFT, fc1, W_ih layer 0) | LSTM layer 0 | 1 | 2 | back (fc2, fc3, Wiener,
+ * iSTFT).  Same kernels and results as umx_hip_infer_segment; the cuts are where the reference's per-chain
+ * (h, c) (lstm.cpp:116-161: read at the start of a layer, left behind at its end) crosses from the GPU that ran
+ * the previous segment (SURVEY 8e "carry" mode): set layer l's state, run layer l, get it, pass it on.
+ * Layer state layout: [4 targets][2 dirs][2: h, c][hidden/2] floats. */
+size_t umx_hip_stream_layer_floats(const umx_hip_ctx *ctx);
+int umx_hip_stream_get_layer(umx_hip_ctx *ctx, int layer, float *host_dst);
+int umx_hip_stream_set_layer(umx_hip_ctx *ctx, int layer, const float *host_src);
+int umx_hip_segment_begin(umx_hip_ctx *ctx, const float *audio_host, int n, unsigned flags);
+int umx_hip_segment_lstm_layer(umx_hip_ctx *ctx, int layer); /* 0, 1, 2 in order */
+int umx_hip_segment_end(umx_hip_ctx *ctx, float *const out_host[4]);
+
 /* Geometry */
 int umx_hip_nb_frames(const umx_hip_ctx *ctx);       /* T = segment_samples/1024 + 1 (dsp.hpp:48) */
 int umx_hip_segment_samples(const umx_hip_ctx *ctx);

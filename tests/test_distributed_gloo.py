@@ -48,6 +48,14 @@ def test_two_rank_gloo_paths(pkg, po, tmp_path):
     assert np.abs(exact[:, :, :first] - one[:, :, :first]).max() < 1e-6
     assert np.abs(exact[:, :, first:] - one[:, :, first:]).max() > 1e-6
 
+    # carry mode (exact): two ranks, per-layer (h, c) handed from segment to segment, must give
+    # the reference's split_inference -- the overlap-add arithmetic is identical, so bit for bit
+    wave2 = pkg.ggml.synth_audio(int(N * 3.3), 13)
+    carry = np.load(tmp_path / "carry_mode.npy")
+    exact2 = np.stack(po.split_inference(om, wave2, N))
+    assert carry.shape == exact2.shape
+    assert np.abs(carry - exact2).max() <= 1e-6 * max(1.0, np.abs(exact2).max())
+
 
 def test_shard_tracks():
     mg = __import__("importlib").import_module("umx_cpp_amd.multigpu")

@@ -154,6 +154,69 @@ def test_pipelined_segments_equal_one_at_a_time(pkg, tmp_path):
     assert (results["wavefront"][1] == results["slots"][1]).all()
 
 
+def test_phased_segment_equals_whole_segment(pkg, small):
+    """umx_hip_segment_begin / _lstm_layer x3 / _end (the cut points of the multi-GPU carry mode) run the
+    same kernels as umx_hip_infer_segment: same bits, same carried state; per-layer get/set round-trips."""
+    eng, om, N = small
+    waves = [pkg.ggml.synth_audio(N, 300 + i) for i in range(3)]
+    eng.stream_reset()
+    whole = [eng.infer_segment(w) for w in waves]
+    st_whole = eng.stream_get()
+    eng.stream_reset()
+    phased = []
+    for w in waves:
+        eng.segment_begin(w)
+        for l in range(3):
+            a = eng.stream_get_layer(l)
+            eng.stream_set_layer(l, a)  # what another GPU would have sent
+            eng.segment_lstm_layer(l)
+        phased.append(eng.segment_end())
+    st_phased = eng.stream_get()
+    for i in range(3):
+        for t in range(4):
+            assert (whole[i][t] == phased[i][t]).all(), (i, t)
+    assert (st_whole == st_phased).all()
+    # the per-layer view is a slice of the whole state: [target][layer][dir][h|c][Hl]
+    Hl = 64
+    full = st_whole.reshape(4, 3, 2, 2, Hl)
+    for l in range(3):
+        assert (eng.stream_get_layer(l).reshape(4, 2, 2, Hl) == full[:, l]).all()
+    # protocol errors are reported, not executed
+    eng.segment_begin(waves[0])
+    with pytest.raises(RuntimeError):
+        eng.segment_lstm_layer(1)
+    with pytest.raises(RuntimeError):
+        eng.infer_segment(waves[0])
+    for l in range(3):
+        eng.segment_lstm_layer(l)
+    eng.segment_end()
+    eng.stream_reset()
+
+
+def test_carry_mode_two_processes_one_gpu(pkg, model_small, tmp_path):
+    """SURVEY 8e "carry" mode: a track's segments alternate between two ranks, each layer's (h, c) travels
+    point to point; the result must be bit-identical to one engine running split_inference."""
+    import socket
+    import subprocess
+    path, om, targets = model_small
+    N, L, seed = 16 * 1024, int(16 * 1024 * 3.4), 77
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = Path(__file__).resolve().parent.parent
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(root / "tests" / "carry_worker.py"), path, str(tmp_path), str(N), str(L), str(seed)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    carry = np.load(tmp_path / "carry.npy")
+    eng = pkg.Engine(targets, 128, N)
+    one = np.stack(pkg.split_inference(pkg.engine_backend(eng), pkg.ggml.synth_audio(L, seed), N))
+    eng.close()
+    assert carry.shape == one.shape
+    assert (carry == one).all()
+
+
 def test_short_chunk_ragged_last_segment(pkg, po, small):
     """n < segment_samples: T stays n_buf/1024+1, the tail is zeros, outputs are (2,n) (a3, a11)."""
     eng, om, N = small

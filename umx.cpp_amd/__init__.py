@@ -97,6 +97,13 @@ def hip_lib():
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.umx_hip_stream_layer_floats.restype = C.c_size_t
+    lib.umx_hip_stream_layer_floats.argtypes = [C.c_void_p]
+    lib.umx_hip_stream_get_layer.argtypes = [C.c_void_p, C.c_int, _fp]
+    lib.umx_hip_stream_set_layer.argtypes = [C.c_void_p, C.c_int, _fp]
+    lib.umx_hip_segment_begin.argtypes = [C.c_void_p, _fp, C.c_int, C.c_uint]
+    lib.umx_hip_segment_lstm_layer.argtypes = [C.c_void_p, C.c_int]
+    lib.umx_hip_segment_end.argtypes = [C.c_void_p, C.POINTER(_fp)]
     _hip = lib
     return lib
 
@@ -106,7 +113,9 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_destroy", "umx_hip_last_error", "umx_h
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
                "umx_hip_stage_times_slot",
-               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile"]
+               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile",
+               "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
+               "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end"]
 
 
 def views_from_file_tensors(targets, quantised=True):
@@ -186,6 +195,34 @@ class Engine:
         a = np.ascontiguousarray(a, np.float32)
         assert a.size == self.lib.umx_hip_stream_floats(self.h)
         self._check(self.lib.umx_hip_stream_set(self.h, a.ctypes.data_as(_fp)))
+
+    def stream_get_layer(self, layer):
+        """(h, c) of LSTM layer `layer`, all chains: [4 targets][2 dirs][2: h, c][hidden/2]."""
+        a = np.empty(self.lib.umx_hip_stream_layer_floats(self.h), np.float32)
+        self._check(self.lib.umx_hip_stream_get_layer(self.h, layer, a.ctypes.data_as(_fp)))
+        return a
+
+    def stream_set_layer(self, layer, a):
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.size == self.lib.umx_hip_stream_layer_floats(self.h)
+        self._check(self.lib.umx_hip_stream_set_layer(self.h, layer, a.ctypes.data_as(_fp)))
+
+    # --- one segment phase by phase (exact multi-GPU carry, multigpu.separate_track_carry_mode) ---
+    def segment_begin(self, wave, flags=0):
+        wave = np.asarray(wave, np.float32)
+        self._phase_n = wave.shape[1]
+        a = np.ascontiguousarray(wave.T).ravel()
+        self._check(self.lib.umx_hip_segment_begin(self.h, a.ctypes.data_as(_fp), self._phase_n, flags))
+
+    def segment_lstm_layer(self, layer):
+        self._check(self.lib.umx_hip_segment_lstm_layer(self.h, layer))
+
+    def segment_end(self):
+        n = self._phase_n
+        outs = [np.empty(2 * n, np.float32) for _ in range(4)]
+        arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs])
+        self._check(self.lib.umx_hip_segment_end(self.h, arr))
+        return [np.ascontiguousarray(o.reshape(n, 2).T) for o in outs]
 
     # --- umx_inference (inference.cpp:12-207) ---
     def infer_segment(self, wave, flags=0):

@@ -145,6 +145,13 @@ struct umx_hip_ctx
     }
     int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors);
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
+    // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
+    int phase_begin(const float *audio_host, int n, unsigned flags);
+    int phase_layer(int layer);
+    int phase_end(float *const out_host[4]);
+    int ph_next = -1; // -1: no phased segment open; 0..2: next LSTM layer; 3: back stage pending
+    int ph_n = 0;
+    unsigned ph_flags = 0;
     int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise);
     int sync_all();
     void launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
@@ -974,6 +981,11 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
             set_error("infer_segment: null output pointer");
             return UMX_ERR_ARG;
         }
+    if (ph_next != -1)
+    {
+        set_error("infer_segment: a phased segment is open (umx_hip_segment_end first)");
+        return UMX_ERR_ARG;
+    }
     UMX_HIP_CHECK(hipSetDevice(device));
     if (wavefront && !(flags & UMX_FLAG_LSTM_STEPWISE) && persistent_ok && 8 * S <= lstm_capacity)
     {
@@ -1026,6 +1038,89 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
     sl.used = true;
     cur = si;
     ++nseg;
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- one segment, phase by phase
+// The same launches as infer_device on slot 0, cut where another GPU's LSTM state has to come in: the
+// caller sets layer l's incoming (h, c) (umx_hip_stream_set_layer) before phase_layer(l) and reads the
+// outgoing one after it.  Used by the exact state-carry pipeline over several GPUs (multigpu.py).
+int umx_hip_ctx::phase_begin(const float *audio_host, int n, unsigned flags)
+{
+    if (!audio_host || n < 1 || n > N)
+    {
+        set_error("segment_begin: need 1 <= n <= segment_samples and non-null audio");
+        return UMX_ERR_ARG;
+    }
+    if (ph_next != -1)
+    {
+        set_error("segment_begin: a phased segment is already open");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    if (int rc = sync_all())
+        return rc;
+    Slot &sl = slot[0];
+    int active[4], nact;
+    active_list(flags, active, nact);
+    last_flags = flags;
+    last_was_wavefront = false;
+    UMX_HIP_CHECK(hipMemcpyAsync(audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, sl.stream));
+    if (int rc = stage_front(sl, sl.stream, audio_in, n, active, nact))
+        return rc;
+    ph_next = 0;
+    ph_n = n;
+    ph_flags = flags;
+    return UMX_OK;
+}
+
+int umx_hip_ctx::phase_layer(int layer)
+{
+    if (ph_next < 0 || ph_next > 2 || layer != ph_next)
+    {
+        set_error("segment_lstm_layer: layers run in order 0, 1, 2 after segment_begin");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    Slot &sl = slot[0];
+    hipStream_t st = sl.stream;
+    int active[4], nact;
+    active_list(ph_flags, active, nact);
+    if (layer > 0)
+    {
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
+        if (nact > 0)
+            launch_gemm(sl, st, G_IH, layer, active, nact, false);
+    }
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
+    if (nact > 0)
+        if (int rc = run_lstm_layer(sl, layer, active, nact, ph_flags & UMX_FLAG_LSTM_STEPWISE))
+            return rc;
+    UMX_HIP_CHECK(hipEventRecord(sl.rec_done[layer], st));
+    ph_next = layer + 1;
+    return UMX_OK;
+}
+
+int umx_hip_ctx::phase_end(float *const out_host[4])
+{
+    if (ph_next != 3 || !out_host)
+    {
+        set_error("segment_end: all three LSTM layers must have run");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    Slot &sl = slot[0];
+    int active[4], nact;
+    active_list(ph_flags, active, nact);
+    ph_next = -1;
+    if (int rc = stage_back(sl, sl.stream, out_dev, ph_n, ph_flags, active, nact))
+        return rc;
+    cur = 0;
+    if (int rc = umx_hip_sync(this))
+        return rc;
+    for (int s = 0; s < 4; ++s)
+        UMX_HIP_CHECK(hipMemcpy(out_host[s], out_dev[s], sizeof(float) * 2 * (size_t)ph_n, hipMemcpyDeviceToHost));
+    slot[0].used = slot[1].used = slot[2].used = false; // drained: nothing for the next segment to wait for
     return UMX_OK;
 }
 
@@ -1137,6 +1232,44 @@ int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src)
     ctx->slot[0].used = ctx->slot[1].used = ctx->slot[2].used = false;
     return UMX_OK;
 }
+
+size_t umx_hip_stream_layer_floats(const umx_hip_ctx *ctx) { return ctx ? (size_t)4 * 4 * ctx->Hl : 0; }
+
+// one layer's (h, c) of all chains: [target][dir][h|c][Hl]
+static int stream_layer_copy(umx_hip_ctx *ctx, int layer, float *host, bool to_host)
+{
+    if (!ctx || !host || layer < 0 || layer > 2)
+        return UMX_ERR_ARG;
+    hipError_t e = hipStreamSynchronize(ctx->slot[0].stream);
+    if (e == hipSuccess && ctx->ph_next < 0) // outside a phased segment other slots may be busy too
+        if (int rc = ctx->sync_all())
+            return rc;
+    const size_t per = (size_t)4 * ctx->Hl;
+    for (int tg = 0; tg < 4 && e == hipSuccess; ++tg)
+    {
+        float *dev = ctx->state + state_off(tg, layer, 0, 0, ctx->Hl);
+        e = to_host ? hipMemcpy(host + tg * per, dev, per * sizeof(float), hipMemcpyDeviceToHost)
+                    : hipMemcpy(dev, host + tg * per, per * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    return UMX_OK;
+}
+int umx_hip_stream_get_layer(umx_hip_ctx *ctx, int layer, float *host_dst) { return stream_layer_copy(ctx, layer, host_dst, true); }
+int umx_hip_stream_set_layer(umx_hip_ctx *ctx, int layer, const float *host_src)
+{
+    return stream_layer_copy(ctx, layer, const_cast<float *>(host_src), false);
+}
+
+int umx_hip_segment_begin(umx_hip_ctx *ctx, const float *audio_host, int n, unsigned flags)
+{
+    return ctx ? ctx->phase_begin(audio_host, n, flags) : UMX_ERR_ARG;
+}
+int umx_hip_segment_lstm_layer(umx_hip_ctx *ctx, int layer) { return ctx ? ctx->phase_layer(layer) : UMX_ERR_ARG; }
+int umx_hip_segment_end(umx_hip_ctx *ctx, float *const out_host[4]) { return ctx ? ctx->phase_end(out_host) : UMX_ERR_ARG; }
 
 int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
                                  unsigned flags)

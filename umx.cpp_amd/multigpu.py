@@ -10,12 +10,18 @@ The unit of work is a segment (umx.cpp:214-227).  What is exact and what is not:
                          (SURVEY F3), so this DEVIATES from it; the overlap-add itself is exact (each
                          output sample has at most two contributors and a + b == b + a in IEEE).  Rank 0
                          gathers the weighted stems with point-to-point transfers and normalises.
-* exact single-track splitting needs the per-layer state hand-off (wavefront of SURVEY 8e); inside one
-  GPU that wavefront is what csrc/engine.hip's two pipeline slots already do; across GPUs it is the next
-  step (`umx_hip_stream_get/set` expose the 32 KB state).
+* `separate_track_carry_mode` -- ONE track, its segments round-robin over ranks, EXACT: the reference
+                         carries every chain's (h, c) from one segment into the next, and layer l
+                         of segment s needs nothing else of segment s-1.  Rank s % world runs segment s phase
+                         by phase (umx_hip_segment_begin / _lstm_layer / _end); before layer l it receives
+                         that layer's 32 KB state from the rank that ran segment s-1 and afterwards sends its
+                         own on: a wavefront over GPUs, point-to-point messages only (no collective has a
+                         role here).  The front (STFT, fc1, W_ih) and back (fc2, fc3, Wiener, iSTFT) stages
+                         of different segments overlap freely.  Bit-identical to the single-GPU result.
+  Inside one GPU the same wavefront is what csrc/engine.hip's two pipeline slots do.
 
-The functions only need a `segment_fn((2,n) float32 array) -> 4 x (2,n)` and are therefore testable on
-CPU with any backend.
+The drivers only need a `segment_fn((2,n) float32 array) -> 4 x (2,n)` or a phased backend (see
+`EnginePhases`) and are therefore testable on CPU with any stand-in backend.
 """
 import numpy as np
 
@@ -51,8 +57,14 @@ def separate_track_reset_mode(segment_fn, reset_fn, wave, segment_samples, dist=
         stems = segment_fn(np.ascontiguousarray(wave[:, off:off + n]))
         w = _weights(n, N)
         local[i] = np.stack([np.asarray(s, np.float32) * w[None, :] for s in stems])  # (4,2,n), pre-weighted
+    return _gather_overlap_add(local, mine, offsets, L, N, dist, rank, world, device)
+
+
+def _gather_overlap_add(local, mine, offsets, L, N, dist, rank, world, device):
+    """Weighted stems of every segment -> rank 0 (point-to-point), overlap-add in segment order, / sum_w."""
+    import torch
     if world > 1:
-        # point-to-point gather of the weighted stems to rank 0 (<= 85 MB per segment at full size)
+        # <= 85 MB per segment at full size
         if rank == 0:
             for i in range(len(offsets)):
                 if i % world != 0:
@@ -72,6 +84,68 @@ def separate_track_reset_mode(segment_fn, reset_fn, wave, segment_samples, dist=
         sum_w[off:off + n] += _weights(n, N)
     out /= sum_w[None, None, :]
     return [out[t] for t in range(4)]
+
+
+class EnginePhases:
+    """Phased backend over the C-ABI (include/umx_hip.h: umx_hip_segment_begin ... umx_hip_stream_set_layer)."""
+
+    def __init__(self, engine, flags=0):
+        self.e, self.flags = engine, flags
+
+    def layer_floats(self):
+        return int(self.e.lib.umx_hip_stream_layer_floats(self.e.h))
+
+    def begin(self, chunk):
+        self.e.segment_begin(chunk, self.flags)
+
+    def layer(self, l):
+        self.e.segment_lstm_layer(l)
+
+    def end(self):
+        return self.e.segment_end()
+
+    def get_layer(self, l):
+        return self.e.stream_get_layer(l)
+
+    def set_layer(self, l, a):
+        self.e.stream_set_layer(l, a)
+
+
+def separate_track_carry_mode(backend, wave, segment_samples, dist=None, rank=0, world=1, device="cpu"):
+    """Exact split of one track over `world` ranks (state-carry wavefront); 4 x (2,L) on rank 0, else None.
+    `backend`: begin(chunk) / layer(l) / end() -> 4 x (2,n) / get_layer(l) / set_layer(l, a) / layer_floats()."""
+    import torch
+    wave = np.asarray(wave, np.float32)
+    L = wave.shape[1]
+    N = segment_samples
+    stride = int((1 - 0.25) * N)  # umx.cpp:181
+    offsets = list(range(0, L, stride))
+    nseg = len(offsets)
+    mine = [i for i in range(nseg) if i % world == rank]
+    nf = backend.layer_floats()
+    local, pending = {}, []
+    for i in mine:
+        off = offsets[i]
+        n = min(N, L - off)
+        backend.begin(np.ascontiguousarray(wave[:, off:off + n]))
+        for l in range(3):
+            if i == 0:
+                backend.set_layer(l, np.zeros(nf, np.float32))  # create_lstm_data: zero state (lstm.cpp:82)
+            elif world > 1:
+                buf = torch.empty(nf, dtype=torch.float32, device=device)
+                dist.recv(buf, src=(i - 1) % world)
+                backend.set_layer(l, buf.cpu().numpy())
+            # world == 1: the state left by segment i-1 is already in place
+            backend.layer(l)
+            if world > 1 and i + 1 < nseg:
+                t = torch.from_numpy(backend.get_layer(l).copy()).to(device)
+                pending.append((dist.isend(t, dst=(i + 1) % world), t))
+        stems = backend.end()
+        w = _weights(n, N)
+        local[i] = np.stack([np.asarray(s, np.float32) * w[None, :] for s in stems])
+    for req, _keep in pending:
+        req.wait()
+    return _gather_overlap_add(local, mine, offsets, L, N, dist, rank, world, device)
 
 
 def timed_region(step_fn, sync_fn, steps, warmup, dist=None, world=1, device=None):
