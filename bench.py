@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
     ap.add_argument("--serial", action="store_true", help="sync after every segment (no cross-segment pipelining)")
+    ap.add_argument("--quantised-resident", action="store_true",
+                    help="BASELINE config 5: u8/u16 weights stay in HBM, dequantised in the GEMM / LSTM loads")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +111,7 @@ def main():
     tmpdir = tempfile.mkdtemp(prefix=f"umx_bench_r{rank}_")
     wpath = os.path.join(tmpdir, "ggml-model-synth-u8.bin")
     pkg.ggml.write_model(wpath, pkg.ggml.synth_weights(H, seed=0), H, compress=False)
-    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank)
+    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=args.quantised_resident)
     T = eng.T
 
     wave = pkg.ggml.synth_audio(N, seed=rank)  # each rank: its own track
@@ -204,6 +206,8 @@ def main():
                        "hidden": H, "segment_samples": N, "frames": T, "stems": 4,
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(
                            eng.lstm_mode(), "?"),
+                       "weights_resident": "u8/u16 (dequantised in the kernels)" if args.quantised_resident else "f32",
+                       "weight_bytes": eng.weight_bytes(),
                        "sharding": f"{world} independent segments (one per rank)"},
             "roofline": roofline,
             "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},

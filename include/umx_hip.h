@@ -69,6 +69,16 @@ typedef struct umx_hip_ctx umx_hip_ctx;
  * Needs 4 x 43 tensors (model.cpp:240-539 name dispatch).  hidden_size % 128 == 0. */
 int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                    const umx_tensor_view *tensors, int n_tensors);
+/* BASELINE config 5 / SURVEY 8(f)1: keep the matrices as stored in the ggml file (u8: fc1, W_ih, W_hh; u16: fc2,
+ * fc3 -- convert-umx-pth-to-ggml.py:127-160) resident in HBM and dequantise q*scale+offset (model.cpp:610-616)
+ * where they are consumed: in the GEMM's B-tile staging and in the LSTM kernel's one-time W_hh register load.
+ * Results are bit-identical to umx_hip_create on the same views; HBM held by weights drops from 452 MB to
+ * ~139 MB for UMX-L (umx_hip_weight_bytes).  Tensors handed over as fp32 views stay fp32.
+ * umx_hip_create honours the environment variable UMX_WEIGHTS_RESIDENT=quantised as the same switch. */
+#define UMX_CREATE_QUANTISED_RESIDENT 0x1u
+int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                      const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
+size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx); /* HBM bytes held by the model's weight matrices */
 void umx_hip_destroy(umx_hip_ctx *ctx);
 const char *umx_hip_last_error(const umx_hip_ctx *ctx); /* never NULL; also valid for ctx == NULL (create errors) */
 

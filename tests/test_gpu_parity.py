@@ -217,6 +217,43 @@ def test_carry_mode_two_processes_one_gpu(pkg, model_small, tmp_path):
     assert (carry == one).all()
 
 
+def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_path):
+    """BASELINE config 5: u8/u16 matrices stay in HBM and are dequantised in the GEMM B-tile staging and the
+    LSTM W_hh register load (q*scale+offset, model.cpp:610-616): same bits as dequantising at load time,
+    a third of the weight memory; persistent and per-step LSTM drivers, small and UMX-L-sized hidden."""
+    path, om, targets = model_small
+    N = 16 * 1024
+    waves = [pkg.ggml.synth_audio(N, 400 + i) for i in range(2)]
+    ref = pkg.Engine(targets, 128, N)
+    qr = pkg.Engine(targets, 128, N, quantised_resident=True)
+    assert qr.weight_bytes() * 2.5 < ref.weight_bytes()
+    for flags in (0, pkg.FLAG_LSTM_STEPWISE):
+        ref.stream_reset()
+        qr.stream_reset()
+        for w in waves:
+            a, b = ref.infer_segment(w, flags), qr.infer_segment(w, flags)
+            for t in range(4):
+                assert (a[t] == b[t]).all(), (flags, t)
+        assert (ref.stream_get() == qr.stream_get()).all()
+    # fp32 views cannot stay quantised: the flag is then a no-op, not an error
+    f32 = pkg.Engine(targets, 128, N, quantised=False, quantised_resident=True)
+    assert f32.weight_bytes() == ref.weight_bytes()
+    for e in (ref, qr, f32):
+        e.close()
+    H, N = 1024, 24 * 1024
+    p = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=31), H, compress=False)
+    ref, qr = pkg.Engine.from_file(p, N), pkg.Engine.from_file(p, N, quantised_resident=True)
+    assert 130e6 < qr.weight_bytes() < 150e6 and 440e6 < ref.weight_bytes() < 470e6
+    w = pkg.ggml.synth_audio(N, 410)
+    a, b = ref.infer_segment(w), qr.infer_segment(w)
+    assert qr.lstm_mode() == 2
+    for t in range(4):
+        assert (a[t] == b[t]).all()
+    ref.close()
+    qr.close()
+
+
 def test_short_chunk_ragged_last_segment(pkg, po, small):
     """n < segment_samples: T stays n_buf/1024+1, the tail is zeros, outputs are (2,n) (a3, a11)."""
     eng, om, N = small

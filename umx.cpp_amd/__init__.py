@@ -74,6 +74,10 @@ def hip_lib():
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(str(path))
     lib.umx_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(TensorView), C.c_int]
+    lib.umx_hip_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(TensorView), C.c_int,
+                                      C.c_uint]
+    lib.umx_hip_weight_bytes.restype = C.c_size_t
+    lib.umx_hip_weight_bytes.argtypes = [C.c_void_p]
     lib.umx_hip_destroy.argtypes = [C.c_void_p]
     lib.umx_hip_last_error.restype = C.c_char_p
     lib.umx_hip_last_error.argtypes = [C.c_void_p]
@@ -108,7 +112,9 @@ def hip_lib():
     return lib
 
 
-HIP_SYMBOLS = ["umx_hip_create", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
+CREATE_QUANTISED_RESIDENT = 0x1
+
+HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
@@ -150,11 +156,15 @@ class Engine:
     Mirrors the call shape of umx.cpp:160-227: create once per track, `infer_segment` per chunk,
     the streaming LSTM state carries over until `stream_reset`."""
 
-    def __init__(self, targets, hidden, segment_samples=SEGMENT_SAMPLES, device=0, quantised=True):
+    def __init__(self, targets, hidden, segment_samples=SEGMENT_SAMPLES, device=0, quantised=True,
+                 quantised_resident=False):
+        """quantised: hand the file's u8/u16 bytes (+ scale/offset) to the engine instead of fp32 arrays;
+        quantised_resident: keep them that way in HBM (BASELINE config 5, umx_hip_create_ex)."""
         self.lib = hip_lib()
         views, self._keep = views_from_file_tensors(targets, quantised)
         h = C.c_void_p()
-        rc = self.lib.umx_hip_create(C.byref(h), device, hidden, segment_samples, views, len(views))
+        rc = self.lib.umx_hip_create_ex(C.byref(h), device, hidden, segment_samples, views, len(views),
+                                        CREATE_QUANTISED_RESIDENT if quantised_resident else 0)
         if rc != UMX_OK:
             raise UmxError(rc, self.lib.umx_hip_last_error(None).decode())
         self.h = h
@@ -163,9 +173,12 @@ class Engine:
         self.T = self.lib.umx_hip_nb_frames(h)
 
     @classmethod
-    def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0):
+    def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0, quantised_resident=False):
         hidden, targets = ggml.read_model(path)
-        return cls(targets, hidden, segment_samples, device)
+        return cls(targets, hidden, segment_samples, device, quantised_resident=quantised_resident)
+
+    def weight_bytes(self):
+        return int(self.lib.umx_hip_weight_bytes(self.h))
 
     def _check(self, rc):
         if rc != UMX_OK:

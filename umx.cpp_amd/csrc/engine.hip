@@ -28,8 +28,18 @@ namespace
 {
 std::string g_create_error = "";
 
+// A GEMM weight kept in HBM as stored in the ggml file (BASELINE config 5): u8 / u16 + (scale, offset);
+// two parameter pairs because W_ih of a layer is two file tensors (forward rows, then reverse rows).
+struct QMat
+{
+    void *q = nullptr;
+    int type = 0; // GemmBType
+    float s[2] = {1.f, 1.f}, o[2] = {0.f, 0.f};
+};
+
 struct TargetBufs // weights of one target (shared by both pipeline slots)
 {
+    QMat fc1_q, ih_q[3], fc2_q, fc3_q; // used instead of the fp32 matrix when .q != nullptr
     float *fc1_w = nullptr, *in_scale = nullptr, *in_mean = nullptr, *bn1[4] = {};
     float *ih_w[3] = {}, *ih_b[3] = {};
     float *fc2_w = nullptr, *bn2[4] = {};
@@ -143,7 +153,11 @@ struct umx_hip_ctx
         UMX_HIP_CHECK(hipMemcpy(*p, h.data(), h.size() * sizeof(T_), hipMemcpyHostToDevice));
         return UMX_OK;
     }
-    int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors);
+    int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors,
+             unsigned create_flags);
+    size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
+    unsigned char *whh_q[3] = {}; // u8-resident W_hh (create flag), same layout as whh[]
+    float whh_s[3][8] = {}, whh_o[3][8] = {};
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
     // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
     int phase_begin(const float *audio_host, int n, unsigned flags);
@@ -201,7 +215,8 @@ bool dequant(const umx_tensor_view &tv, size_t expect, std::vector<float> &out)
 }
 } // namespace
 
-int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors)
+int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors,
+                      unsigned create_flags)
 {
     if (hidden <= 0 || hidden % 128 != 0 || hidden > 2048)
     {
@@ -260,8 +275,61 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         return true;
     };
 
+    const bool keepq = create_flags & UMX_CREATE_QUANTISED_RESIDENT;
+    auto view = [&](int tg, const std::string &name) -> const umx_tensor_view * {
+        auto it = idx[tg].find(name);
+        return it == idx[tg].end() ? nullptr : it->second;
+    };
+    auto nelems = [](const umx_tensor_view *tv) {
+        size_t n = 1;
+        for (int i = 0; i < tv->n_dims; ++i)
+            n *= (size_t)tv->ne[i];
+        return n;
+    };
+    // Upload `rows` x `cols` of a u8/u16 tensor as stored, into a (rows_pad x cols_pad) device matrix; padding
+    // is q = 0 (any finite weight is fine there: padded K columns meet zero activations, padded N rows are
+    // never stored).  rowmap (optional) = source row of each destination row.
+    auto upload_q = [&](void **dst, const umx_tensor_view *tv, int rows, int cols, int rows_pad, int cols_pad,
+                        const std::vector<int> *rowmap, size_t dst_row0, size_t total_rows) -> int {
+        const size_t esz = tv->dtype == UMX_DTYPE_U8 ? 1 : 2;
+        if (!*dst)
+        {
+            void *q = nullptr;
+            UMX_HIP_CHECK(hipMalloc(&q, total_rows * cols_pad * esz));
+            UMX_HIP_CHECK(hipMemset(q, 0, total_rows * cols_pad * esz));
+            allocs.push_back(q);
+            *dst = q;
+            weight_bytes += total_rows * cols_pad * esz;
+        }
+        std::vector<unsigned char> host((size_t)rows_pad * cols_pad * esz, 0);
+        const unsigned char *src = static_cast<const unsigned char *>(tv->data);
+        for (int r = 0; r < rows; ++r)
+        {
+            const int sr = rowmap ? (*rowmap)[r] : r;
+            memcpy(&host[(size_t)r * cols_pad * esz], src + (size_t)sr * cols * esz, (size_t)cols * esz);
+        }
+        UMX_HIP_CHECK(hipMemcpy(static_cast<unsigned char *>(*dst) + dst_row0 * cols_pad * esz, host.data(), host.size(),
+                                hipMemcpyHostToDevice));
+        return UMX_OK;
+    };
+    auto is_q = [&](const umx_tensor_view *tv, int dtype, size_t expect) {
+        return keepq && tv && tv->dtype == dtype && nelems(tv) == expect;
+    };
+
     const int G = 4 * Hl; // gate rows per direction
     std::vector<float> whh_h[3], bhh_h[3];
+    std::vector<unsigned char> whh_qh[3];
+    bool whh_all_u8 = keepq;
+    for (int tg = 0; tg < 4 && whh_all_u8; ++tg)
+        for (int l = 0; l < 3; ++l)
+            for (int dir = 0; dir < 2; ++dir)
+            {
+                const umx_tensor_view *tv = view(tg, "lstm.weight_hh_l" + std::to_string(l) + (dir ? "_reverse" : ""));
+                whh_all_u8 = whh_all_u8 && tv && tv->dtype == UMX_DTYPE_U8 && nelems(tv) == (size_t)G * Hl;
+            }
+    if (whh_all_u8)
+        for (int l = 0; l < 3; ++l)
+            whh_qh[l].assign((size_t)8 * S * Hl * 64, 0);
     for (int l = 0; l < 3; ++l)
     {
         whh_h[l].assign((size_t)8 * S * Hl * 64, 0.f);
@@ -301,13 +369,25 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         if (int rc = upload(&b.out_mean, w))
             return rc;
         // fc1 (H x 2974) -> (H x KX), zero K padding
-        if (!get(tg, "fc1.weight", (size_t)H * NIN, v))
-            return UMX_ERR_MODEL;
-        w.assign((size_t)H * KX, 0.f);
-        for (int o = 0; o < H; ++o)
-            memcpy(&w[(size_t)o * KX], &v[(size_t)o * NIN], sizeof(float) * NIN);
-        if (int rc = upload(&b.fc1_w, w))
-            return rc;
+        if (const umx_tensor_view *tv = view(tg, "fc1.weight"); is_q(tv, UMX_DTYPE_U8, (size_t)H * NIN))
+        {
+            if (int rc = upload_q(&b.fc1_q.q, tv, H, NIN, H, KX, nullptr, 0, H))
+                return rc;
+            b.fc1_q.type = BQ_U8;
+            b.fc1_q.s[0] = tv->scale;
+            b.fc1_q.o[0] = tv->offset;
+        }
+        else
+        {
+            if (!get(tg, "fc1.weight", (size_t)H * NIN, v))
+                return UMX_ERR_MODEL;
+            w.assign((size_t)H * KX, 0.f);
+            for (int o = 0; o < H; ++o)
+                memcpy(&w[(size_t)o * KX], &v[(size_t)o * NIN], sizeof(float) * NIN);
+            if (int rc = upload(&b.fc1_w, w))
+                return rc;
+            weight_bytes += w.size() * sizeof(float);
+        }
         const char *bnn[4] = {"running_mean", "running_var", "weight", "bias"};
         for (int k = 0; k < 4; ++k)
         {
@@ -326,29 +406,64 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload(&b.bn3[k], w))
                 return rc;
         }
-        if (!get(tg, "fc2.weight", (size_t)H * 2 * H, v))
-            return UMX_ERR_MODEL;
-        if (int rc = upload(&b.fc2_w, v))
-            return rc;
-        if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
-            return UMX_ERR_MODEL;
-        w.assign((size_t)NOUT_PAD * H, 0.f);
-        memcpy(w.data(), v.data(), sizeof(float) * (size_t)NOUT * H);
-        if (int rc = upload(&b.fc3_w, w))
-            return rc;
+        if (const umx_tensor_view *tv = view(tg, "fc2.weight"); is_q(tv, UMX_DTYPE_U16, (size_t)H * 2 * H))
+        {
+            if (int rc = upload_q(&b.fc2_q.q, tv, H, 2 * H, H, 2 * H, nullptr, 0, H))
+                return rc;
+            b.fc2_q.type = BQ_U16;
+            b.fc2_q.s[0] = tv->scale;
+            b.fc2_q.o[0] = tv->offset;
+        }
+        else
+        {
+            if (!get(tg, "fc2.weight", (size_t)H * 2 * H, v))
+                return UMX_ERR_MODEL;
+            if (int rc = upload(&b.fc2_w, v))
+                return rc;
+            weight_bytes += v.size() * sizeof(float);
+        }
+        if (const umx_tensor_view *tv = view(tg, "fc3.weight"); is_q(tv, UMX_DTYPE_U16, (size_t)NOUT * H))
+        {
+            if (int rc = upload_q(&b.fc3_q.q, tv, NOUT, H, NOUT_PAD, H, nullptr, 0, NOUT_PAD))
+                return rc;
+            b.fc3_q.type = BQ_U16;
+            b.fc3_q.s[0] = tv->scale;
+            b.fc3_q.o[0] = tv->offset;
+        }
+        else
+        {
+            if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
+                return UMX_ERR_MODEL;
+            w.assign((size_t)NOUT_PAD * H, 0.f);
+            memcpy(w.data(), v.data(), sizeof(float) * (size_t)NOUT * H);
+            if (int rc = upload(&b.fc3_w, w))
+                return rc;
+            weight_bytes += w.size() * sizeof(float);
+        }
         // LSTM: permute gate rows so a workgroup's 64 columns (g,u) are contiguous
         for (int l = 0; l < 3; ++l)
         {
-            std::vector<float> ihw((size_t)2 * G * H), ihb((size_t)2 * G);
+            const umx_tensor_view *ihv[2] = {view(tg, "lstm.weight_ih_l" + std::to_string(l)),
+                                             view(tg, "lstm.weight_ih_l" + std::to_string(l) + "_reverse")};
+            const bool ih_q = is_q(ihv[0], UMX_DTYPE_U8, (size_t)G * H) && is_q(ihv[1], UMX_DTYPE_U8, (size_t)G * H);
+            std::vector<float> ihw(ih_q ? 0 : (size_t)2 * G * H), ihb((size_t)2 * G);
             for (int dir = 0; dir < 2; ++dir)
             {
                 const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
                 std::vector<float> wih, whhv, bih, bhhv;
-                if (!get(tg, "lstm.weight_ih" + sfx, (size_t)G * H, wih) ||
-                    !get(tg, "lstm.weight_hh" + sfx, (size_t)G * Hl, whhv) ||
+                if ((!ih_q && !get(tg, "lstm.weight_ih" + sfx, (size_t)G * H, wih)) ||
+                    (!whh_all_u8 && !get(tg, "lstm.weight_hh" + sfx, (size_t)G * Hl, whhv)) ||
                     !get(tg, "lstm.bias_ih" + sfx, G, bih) || !get(tg, "lstm.bias_hh" + sfx, G, bhhv))
                     return UMX_ERR_MODEL;
                 const int chain = tg * 2 + dir;
+                const umx_tensor_view *hhv = view(tg, "lstm.weight_hh" + sfx);
+                const unsigned char *hhq = whh_all_u8 ? static_cast<const unsigned char *>(hhv->data) : nullptr;
+                if (whh_all_u8)
+                {
+                    whh_s[l][chain] = hhv->scale;
+                    whh_o[l][chain] = hhv->offset;
+                }
+                std::vector<int> rowmap(G); // destination gate-interleaved row -> PyTorch gate row
                 for (int sl = 0; sl < S; ++sl)
                     for (int g = 0; g < 4; ++g)
                         for (int u = 0; u < 16; ++u)
@@ -356,23 +471,53 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                             const int row = g * Hl + sl * 16 + u; // PyTorch gate row (i|f|g|o blocks)
                             const int col = u * 4 + g; // the 4 gates of a unit share a DPP quad
                             const size_t n = (size_t)dir * G + (size_t)sl * 64 + col;
-                            memcpy(&ihw[n * H], &wih[(size_t)row * H], sizeof(float) * H);
+                            rowmap[sl * 64 + col] = row;
+                            if (!ih_q)
+                                memcpy(&ihw[n * H], &wih[(size_t)row * H], sizeof(float) * H);
                             ihb[n] = bih[row];
                             bhh_h[l][((size_t)chain * S + sl) * 64 + col] = bhhv[row];
                             for (int k = 0; k < Hl; ++k)
-                                whh_h[l][(((size_t)chain * S + sl) * Hl + k) * 64 + col] = whhv[(size_t)row * Hl + k];
+                            {
+                                const size_t di = (((size_t)chain * S + sl) * Hl + k) * 64 + col;
+                                if (whh_all_u8)
+                                    whh_qh[l][di] = hhq[(size_t)row * Hl + k];
+                                else
+                                    whh_h[l][di] = whhv[(size_t)row * Hl + k];
+                            }
                         }
+                if (ih_q)
+                {
+                    if (int rc = upload_q(&b.ih_q[l].q, ihv[dir], G, H, G, H, &rowmap, (size_t)dir * G, (size_t)2 * G))
+                        return rc;
+                    b.ih_q[l].type = BQ_U8;
+                    b.ih_q[l].s[dir] = ihv[dir]->scale;
+                    b.ih_q[l].o[dir] = ihv[dir]->offset;
+                }
             }
-            if (int rc = upload(&b.ih_w[l], ihw))
-                return rc;
+            if (!ih_q)
+            {
+                if (int rc = upload(&b.ih_w[l], ihw))
+                    return rc;
+                weight_bytes += ihw.size() * sizeof(float);
+            }
             if (int rc = upload(&b.ih_b[l], ihb))
                 return rc;
         }
     }
     for (int l = 0; l < 3; ++l)
     {
-        if (int rc = upload(&whh[l], whh_h[l]))
-            return rc;
+        if (whh_all_u8)
+        {
+            if (int rc = upload(&whh_q[l], whh_qh[l]))
+                return rc;
+            weight_bytes += whh_qh[l].size();
+        }
+        else
+        {
+            if (int rc = upload(&whh[l], whh_h[l]))
+                return rc;
+            weight_bytes += whh_h[l].size() * sizeof(float);
+        }
         if (int rc = upload(&bhh[l], bhh_h[l]))
             return rc;
     }
@@ -429,7 +574,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     // the fused three-segment LSTM launches of lstm_wavefront.h (Hl = 512 only; exact but measured slower)
     wavefront = false;
     if (const char *e = getenv("UMX_PIPELINE"))
-        if (std::string(e) == "wavefront" && Hl == LSTM_WF_HL)
+        if (std::string(e) == "wavefront" && Hl == LSTM_WF_HL && !whh_q[0]) // (the experiment knows fp32 W_hh only)
             wavefront = true;
     nslots = wavefront ? 3 : 2;
     for (int si = 0; si < nslots; ++si)
@@ -520,14 +665,18 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 lstm_capacity = std::min(lstm_capacity, 2 * 8 * S - 1);
     }
     // dynamic LDS > 64 KiB must be opted into
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_IH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    {
+        const void *gemms[8] = {reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1, BQ_F32>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1, BQ_U8>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_IH, BQ_F32>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_IH, BQ_U8>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC2, BQ_F32>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC2, BQ_U16>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3, BQ_F32>),
+                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3, BQ_U16>)};
+        for (const void *fn : gemms)
+            UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    }
     UMX_HIP_CHECK(hipDeviceSynchronize());
     return UMX_OK;
 }
@@ -552,7 +701,13 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
     hipStream_t st = sl.stream;
     LstmArgs a;
     memset(&a, 0, sizeof a);
-    a.W = whh[layer];
+    a.W = whh[layer];      // nullptr when W_hh is u8-resident
+    a.Wq = whh_q[layer];
+    for (int c = 0; c < 8; ++c)
+    {
+        a.wsc[c] = whh_s[layer][c];
+        a.wof[c] = whh_o[layer][c];
+    }
     a.bhh = bhh[layer];
     a.state = state;
     a.hbuf = sl.hbuf;
@@ -680,13 +835,42 @@ void umx_hip_ctx::launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, con
             break;
         }
     }
+    // quantised-resident B (config 5): all active targets were loaded the same way
+    int bq = BQ_F32;
+    for (int i = 0; i < nact; ++i)
+    {
+        const TargetBufs &b = tb[active[i]];
+        const QMat &q = mode == G_FC1 ? b.fc1_q : mode == G_IH ? b.ih_q[layer] : mode == G_FC2 ? b.fc2_q : b.fc3_q;
+        GemmTarget &t = g.t[i];
+        t.bsplit = mode == G_IH ? 2 * H : 0x7fffffff; // W_ih rows >= 4*Hl belong to the reverse direction's tensor
+        t.bs[0] = t.bs[1] = 1.f;
+        if (q.q)
+        {
+            t.Bq = q.q;
+            t.bs[0] = q.s[0]; t.bs[1] = q.s[1];
+            t.bo[0] = q.o[0]; t.bo[1] = q.o[1];
+            bq = q.type;
+        }
+    }
     const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
     switch (mode)
     {
-    case G_FC1: hipLaunchKernelGGL(gemm_tn_kernel<G_FC1>, grid, block, GEMM_LDS_BYTES, st, g); break;
-    case G_IH: hipLaunchKernelGGL(gemm_tn_kernel<G_IH>, grid, block, GEMM_LDS_BYTES, st, g); break;
-    case G_FC2: hipLaunchKernelGGL(gemm_tn_kernel<G_FC2>, grid, block, GEMM_LDS_BYTES, st, g); break;
-    default: hipLaunchKernelGGL(gemm_tn_kernel<G_FC3>, grid, block, GEMM_LDS_BYTES, st, g); break;
+    case G_FC1:
+        if (bq == BQ_U8) hipLaunchKernelGGL((gemm_tn_kernel<G_FC1, BQ_U8>), grid, block, GEMM_LDS_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<G_FC1, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
+        break;
+    case G_IH:
+        if (bq == BQ_U8) hipLaunchKernelGGL((gemm_tn_kernel<G_IH, BQ_U8>), grid, block, GEMM_LDS_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<G_IH, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
+        break;
+    case G_FC2:
+        if (bq == BQ_U16) hipLaunchKernelGGL((gemm_tn_kernel<G_FC2, BQ_U16>), grid, block, GEMM_LDS_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<G_FC2, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
+        break;
+    default:
+        if (bq == BQ_U16) hipLaunchKernelGGL((gemm_tn_kernel<G_FC3, BQ_U16>), grid, block, GEMM_LDS_BYTES, st, g);
+        else hipLaunchKernelGGL((gemm_tn_kernel<G_FC3, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
+        break;
     }
 }
 
@@ -1128,8 +1312,22 @@ int umx_hip_ctx::phase_end(float *const out_host[4])
 extern "C"
 {
 
+int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                      const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                    const umx_tensor_view *tensors, int n_tensors)
+{
+    unsigned cf = 0;
+    if (const char *e = getenv("UMX_WEIGHTS_RESIDENT")) // lets umx-cli switch without an API change
+        if (std::string(e) == "quantised" || std::string(e) == "quantized")
+            cf |= UMX_CREATE_QUANTISED_RESIDENT;
+    return umx_hip_create_ex(out, device, hidden_size, segment_samples, tensors, n_tensors, cf);
+}
+
+size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx) { return ctx ? ctx->weight_bytes : 0; }
+
+int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                      const umx_tensor_view *tensors, int n_tensors, unsigned create_flags)
 {
     if (!out || !tensors)
     {
@@ -1138,7 +1336,7 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
     }
     *out = nullptr;
     umx_hip_ctx *c = new umx_hip_ctx;
-    int rc = c->init(device, hidden_size, segment_samples, tensors, n_tensors);
+    int rc = c->init(device, hidden_size, segment_samples, tensors, n_tensors, create_flags);
     if (rc != UMX_OK)
     {
         g_create_error = c->err;

@@ -40,6 +40,12 @@ struct GemmTarget
     const float *q0, *q1;           // FC1: input scale, mean [KX]; FC3: output scale, mean [NOUT_PAD]
     const float *aux;               // FC3: mix_mag
     float *dbg;                     // FC3: optional mask tap [T][NOUT]
+    // BQ != 0: B stays as stored in the ggml file (u8 / u16, model.cpp:578-619) and is dequantised while it
+    // is staged into LDS: w = q * scale + offset in fp32 (model.cpp:610-616).  Rows >= bsplit use the second
+    // (scale, offset) pair (W_ih: forward and reverse direction are two tensors).
+    const void *Bq;
+    float bs[2], bo[2];
+    int bsplit;
 };
 
 struct GemmArgs
@@ -59,7 +65,25 @@ __device__ __forceinline__ float4 scale_shift(float4 a, float4 sc, float4 mn)
 // Register budget of the two-slot pipeline (engine.hip): two GEMM blocks (136 VGPRs allocated) must fit a CU
 // beside two 8-wave LSTM workgroups of the other slot (104 each): 2 x 104 + 2 x 136 = 480 <= 512 per SIMD lane.
 // An LSTM kernel above 120 VGPRs halves the overlapped GEMMs' occupancy (measured: 0.9 -> 2.2 ms).
-template <int MODE> __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs args)
+enum GemmBType
+{
+    BQ_F32 = 0,
+    BQ_U8 = 1,
+    BQ_U16 = 2
+};
+
+__device__ __forceinline__ float4 deq_u8x4(unsigned p, float sc, float of)
+{
+    return make_float4((float)(p & 255u) * sc + of, (float)((p >> 8) & 255u) * sc + of,
+                       (float)((p >> 16) & 255u) * sc + of, (float)(p >> 24) * sc + of);
+}
+__device__ __forceinline__ float4 deq_u16x4(uint2 p, float sc, float of)
+{
+    return make_float4((float)(p.x & 65535u) * sc + of, (float)(p.x >> 16) * sc + of,
+                       (float)(p.y & 65535u) * sc + of, (float)(p.y >> 16) * sc + of);
+}
+
+template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GemmTarget tg = args.t[blockIdx.z];
@@ -75,6 +99,9 @@ template <int MODE> __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Gem
     const int ld_row = tid >> 3, ld_kc = (tid & 7) * 4;
     const float *gA = tg.A + (size_t)(m0 + ld_row) * lda + ld_kc;
     const float *gB = tg.B + (size_t)(n0 + ld_row) * K + ld_kc;
+    const unsigned char *gB8 = static_cast<const unsigned char *>(tg.Bq) + (size_t)(n0 + ld_row) * K + ld_kc;
+    const unsigned short *gB16 = static_cast<const unsigned short *>(tg.Bq) + (size_t)(n0 + ld_row) * K + ld_kc;
+    const float bsc = tg.bs[n0 >= tg.bsplit ? 1 : 0], bof = tg.bo[n0 >= tg.bsplit ? 1 : 0]; // block-uniform
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 
 #define UMX_GLOAD(k0)                                                                                  \
@@ -83,10 +110,27 @@ template <int MODE> __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Gem
         ra1 = *reinterpret_cast<const float4 *>(gA + (size_t)(32) * lda + (k0));                       \
         ra2 = *reinterpret_cast<const float4 *>(gA + (size_t)(64) * lda + (k0));                       \
         ra3 = *reinterpret_cast<const float4 *>(gA + (size_t)(96) * lda + (k0));                       \
-        rb0 = *reinterpret_cast<const float4 *>(gB + (size_t)(0) * K + (k0));                          \
-        rb1 = *reinterpret_cast<const float4 *>(gB + (size_t)(32) * K + (k0));                         \
-        rb2 = *reinterpret_cast<const float4 *>(gB + (size_t)(64) * K + (k0));                         \
-        rb3 = *reinterpret_cast<const float4 *>(gB + (size_t)(96) * K + (k0));                         \
+        if (BQ == BQ_F32)                                                                              \
+        {                                                                                              \
+            rb0 = *reinterpret_cast<const float4 *>(gB + (size_t)(0) * K + (k0));                      \
+            rb1 = *reinterpret_cast<const float4 *>(gB + (size_t)(32) * K + (k0));                     \
+            rb2 = *reinterpret_cast<const float4 *>(gB + (size_t)(64) * K + (k0));                     \
+            rb3 = *reinterpret_cast<const float4 *>(gB + (size_t)(96) * K + (k0));                     \
+        }                                                                                              \
+        else if (BQ == BQ_U8)                                                                          \
+        {                                                                                              \
+            rb0 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(0) * K + (k0)), bsc, bof);   \
+            rb1 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(32) * K + (k0)), bsc, bof);  \
+            rb2 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(64) * K + (k0)), bsc, bof);  \
+            rb3 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(96) * K + (k0)), bsc, bof);  \
+        }                                                                                              \
+        else                                                                                           \
+        {                                                                                              \
+            rb0 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(0) * K + (k0)), bsc, bof);    \
+            rb1 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(32) * K + (k0)), bsc, bof);   \
+            rb2 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(64) * K + (k0)), bsc, bof);   \
+            rb3 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(96) * K + (k0)), bsc, bof);   \
+        }                                                                                              \
         if (MODE == G_FC1)                                                                             \
         { /* inference.cpp:78-83: x*input_scale + input_mean (F8 order), fused into the A load */      \
             const float4 sc = *reinterpret_cast<const float4 *>(tg.q0 + (k0) + ld_kc);                 \

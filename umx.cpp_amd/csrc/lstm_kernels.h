@@ -49,6 +49,8 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 struct LstmArgs
 {
     const float *W;   // this layer: [chains][S][Hl][64]
+    const unsigned char *Wq; // or (W == nullptr) the same layout as stored in the ggml file, u8: w = q*wsc+wof
+    float wsc[8], wof[8];    // per chain (weight_hh_l{layer}[_reverse] of each target), model.cpp:610-616
     const float *bhh; // [chains][S][64]
     const float *P[4];
     float *out[4];    // out[target][t*ldo + col0 + dir*Hl + unit]
@@ -75,6 +77,21 @@ __host__ __device__ inline size_t granule_index(int slot, int chain, int k, int 
     return ((size_t)(slot * 8 + chain) * S + (k >> 4)) * LSTM_SLICE_STRIDE + (k & 15);
 }
 __host__ __device__ inline size_t granule_count(int S) { return (size_t)2 * 8 * S * LSTM_SLICE_STRIDE; }
+
+// element (k, col) of a chain-slice's W_hh block [Hl][64], fp32-resident or u8-resident
+__device__ __forceinline__ float whh_at(const LstmArgs &a, int wchain, size_t idx)
+{
+    return a.W ? a.W[idx] : (float)a.Wq[idx] * a.wsc[wchain] + a.wof[wchain];
+}
+__device__ __forceinline__ float4 whh_at4(const LstmArgs &a, int wchain, size_t idx) // idx % 4 == 0
+{
+    if (a.W)
+        return *reinterpret_cast<const float4 *>(a.W + idx);
+    const unsigned p = *reinterpret_cast<const unsigned *>(a.Wq + idx);
+    const float sc = a.wsc[wchain], of = a.wof[wchain];
+    return make_float4((float)(p & 255u) * sc + of, (float)((p >> 8) & 255u) * sc + of,
+                       (float)((p >> 16) & 255u) * sc + of, (float)(p >> 24) * sc + of);
+}
 
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); } // lstm.cpp:36-39
 
@@ -163,7 +180,7 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
         hs[i] = hprev[i];
     __syncthreads();
     const int kpw = Hl >> 3;
-    const float *Wc = a.W + ((size_t)wchain * a.S + slice) * Hl * 64 + l; // column l, stride 64 per k
+    const size_t Wc0 = ((size_t)wchain * a.S + slice) * Hl * 64 + l; // column l, stride 64 per k
     float partial;
     if (kpw == 64)
     {
@@ -177,8 +194,8 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
             {
                 const int ke = 64 * w + 16 * r + ((u + rdir * n) & 15);
                 const int ko = 64 * w + 16 * r + ((u + rdir * (n + 1)) & 15);
-                acc_e = fmaf(Wc[(size_t)ke * 64], hs[ke], acc_e);
-                acc_o = fmaf(Wc[(size_t)ko * 64], hs[ko], acc_o);
+                acc_e = fmaf(whh_at(a, wchain, Wc0 + (size_t)ke * 64), hs[ke], acc_e);
+                acc_o = fmaf(whh_at(a, wchain, Wc0 + (size_t)ko * 64), hs[ko], acc_o);
             }
             pr[r] = acc_e + acc_o;
 #else
@@ -186,7 +203,7 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
             for (int n = 0; n < 16; ++n)
             {
                 const int k = 64 * w + 16 * r + ((u + rdir * n) & 15);
-                acc = fmaf(Wc[(size_t)k * 64], hs[k], acc);
+                acc = fmaf(whh_at(a, wchain, Wc0 + (size_t)k * 64), hs[k], acc);
             }
             pr[r] = acc;
 #endif
@@ -199,8 +216,8 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
         for (int i = 0; i < kpw; i += 2)
         {
             float2v wv, hv;
-            wv.x = Wc[(size_t)(w * kpw + i) * 64];
-            wv.y = Wc[(size_t)(w * kpw + i + 1) * 64];
+            wv.x = whh_at(a, wchain, Wc0 + (size_t)(w * kpw + i) * 64);
+            wv.y = whh_at(a, wchain, Wc0 + (size_t)(w * kpw + i + 1) * 64);
             hv.x = hs[w * kpw + i];
             hv.y = hs[w * kpw + i + 1];
             acc = __builtin_elementwise_fma(wv, hv, acc);
@@ -416,22 +433,22 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     {
         int kidx[16];
         KidxDpp<15>::run(w * KPW + l, kidx);
-        const float *Wb = a.W + ((size_t)wchain * a.S + slice) * Hl * 64 + 4 * (l & 15);
+        const size_t Wb = ((size_t)wchain * a.S + slice) * Hl * 64 + 4 * (l & 15);
 #pragma unroll
         for (int n = 0; n < 16; ++n)
         {
-            const float4 v = *reinterpret_cast<const float4 *>(Wb + (size_t)kidx[n] * 64);
+            const float4 v = whh_at4(a, wchain, Wb + (size_t)kidx[n] * 64);
             Wd.set(n, v);
         }
     }
     else
     {
-        const float *Wp = a.W + (((size_t)wchain * a.S + slice) * Hl + (size_t)w * KPW) * 64 + l;
+        const size_t Wp = (((size_t)wchain * a.S + slice) * Hl + (size_t)w * KPW) * 64 + l;
 #pragma unroll
         for (int i = 0; i < KPW / 2; ++i)
         {
-            W[i].x = Wp[(size_t)(2 * i) * 64];
-            W[i].y = Wp[(size_t)(2 * i + 1) * 64];
+            W[i].x = whh_at(a, wchain, Wp + (size_t)(2 * i) * 64);
+            W[i].y = whh_at(a, wchain, Wp + (size_t)(2 * i + 1) * 64);
         }
     }
     // Wave roles: waves 0..7 poll h, multiply their k-range and leave 64 partial sums in LDS; wave 8
