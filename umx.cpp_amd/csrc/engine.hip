@@ -852,7 +852,11 @@ void umx_hip_ctx::launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, con
             bq = q.type;
         }
     }
+#if GEMM_SWIZZLE
+    const dim3 grid((unsigned)round_up((g.N / GEMM_BN) * (g.M / GEMM_BM), 8), 1, nact), block(256);
+#else
     const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
+#endif
     switch (mode)
     {
     case G_FC1:

@@ -54,6 +54,12 @@ struct GemmArgs
     int M, N, K, lda, ldc, T;
 };
 
+#ifndef GEMM_SWIZZLE
+#define GEMM_SWIZZLE 1
+#endif
+#ifndef GEMM_GROUP_M
+#define GEMM_GROUP_M 8
+#endif
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32, GEMM_LD = 36;
 constexpr int GEMM_LDS_BYTES = 2 * 2 * 128 * GEMM_LD * 4; // 73,728
 
@@ -89,7 +95,26 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
     const GemmTarget tg = args.t[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+#if GEMM_SWIZZLE
+    // 1-D grid, padded to a multiple of 8.  Workgroups are dealt round-robin to the 8 XCDs (each with its own
+    // L2): XCD x gets a contiguous run of tiles, walked in 8-tile-high column groups, so the ~64 tiles an XCD
+    // has in flight form a compact patch that shares A and B K-slices through that XCD's L2.
+    int tile_m, tile_n;
+    {
+        const int gx = args.N / GEMM_BN, gy = args.M / GEMM_BM, total = gx * gy;
+        const int chunk = (total + 7) >> 3;
+        const int v = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= chunk || v >= total)
+            return;
+        const int per_group = GEMM_GROUP_M * gx, group = v / per_group, first_m = group * GEMM_GROUP_M;
+        const int gsize = min(gy - first_m, GEMM_GROUP_M), in_group = v - group * per_group;
+        tile_m = first_m + in_group % gsize;
+        tile_n = in_group / gsize;
+    }
+    const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+#else
     const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
+#endif
     const int K = args.K, lda = args.lda;
 
     float *const sA0 = smem, *const sB0 = smem + 128 * GEMM_LD;
