@@ -54,6 +54,13 @@ struct GemmArgs
     int M, N, K, lda, ldc, T;
 };
 
+// Which modes pin the next tile's global loads at the top of the K tile (see UMX_GLOAD_PART).  fc1 gains 20 %
+// (its K loop is long and its A prologue loads two extra vectors); for the other modes two blocks per CU
+// already hide the latency and the longer live ranges would push them past the 152-VGPR budget of the
+// two-slot pipeline (see below), so they keep the compiler's order.
+#ifndef GEMM_PIN_LOADS
+#define GEMM_PIN_LOADS(MODE) ((MODE) == G_FC1)
+#endif
 #ifndef GEMM_SWIZZLE
 #define GEMM_SWIZZLE 1
 #endif
@@ -127,57 +134,56 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
     const unsigned char *gB8 = static_cast<const unsigned char *>(tg.Bq) + (size_t)(n0 + ld_row) * K + ld_kc;
     const unsigned short *gB16 = static_cast<const unsigned short *>(tg.Bq) + (size_t)(n0 + ld_row) * K + ld_kc;
     const float bsc = tg.bs[n0 >= tg.bsplit ? 1 : 0], bof = tg.bo[n0 >= tg.bsplit ? 1 : 0]; // block-uniform
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rsc, rmn;
+    uint2 rq0, rq1, rq2, rq3;
+    rb0 = rb1 = rb2 = rb3 = rsc = rmn = make_float4(0.f, 0.f, 0.f, 0.f);
+    rq0 = rq1 = rq2 = rq3 = make_uint2(0u, 0u);
 
+// Global loads of K tile k0, part j (0..3) = one 32-row group of A and of B.  Loads only: everything that
+// consumes the loaded registers (input scaling, dequantisation) happens in UMX_SSTORE, a whole tile of
+// MFMAs later, and __builtin_amdgcn_sched_barrier pins the loads where they are written -- left alone, the
+// scheduler sinks them to the end of the tile (right before the LDS stores) and every K tile then waits
+// out a full memory latency.
+#define UMX_GLOAD_PART(j, ra, rbf, rbq, k0)                                                            \
+    {                                                                                                  \
+        ra = *reinterpret_cast<const float4 *>(gA + (size_t)(32 * (j)) * lda + (k0));                  \
+        if (BQ == BQ_F32)                                                                              \
+            rbf = *reinterpret_cast<const float4 *>(gB + (size_t)(32 * (j)) * K + (k0));               \
+        else if (BQ == BQ_U8)                                                                          \
+            rbq.x = *reinterpret_cast<const unsigned *>(gB8 + (size_t)(32 * (j)) * K + (k0));          \
+        else                                                                                           \
+            rbq = *reinterpret_cast<const uint2 *>(gB16 + (size_t)(32 * (j)) * K + (k0));              \
+        if (MODE == G_FC1 && (j) == 0)                                                                 \
+        {                                                                                              \
+            rsc = *reinterpret_cast<const float4 *>(tg.q0 + (k0) + ld_kc);                             \
+            rmn = *reinterpret_cast<const float4 *>(tg.q1 + (k0) + ld_kc);                             \
+        }                                                                                              \
+        if (GEMM_PIN_LOADS(MODE))                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
 #define UMX_GLOAD(k0)                                                                                  \
     {                                                                                                  \
-        ra0 = *reinterpret_cast<const float4 *>(gA + (size_t)(0) * lda + (k0));                        \
-        ra1 = *reinterpret_cast<const float4 *>(gA + (size_t)(32) * lda + (k0));                       \
-        ra2 = *reinterpret_cast<const float4 *>(gA + (size_t)(64) * lda + (k0));                       \
-        ra3 = *reinterpret_cast<const float4 *>(gA + (size_t)(96) * lda + (k0));                       \
-        if (BQ == BQ_F32)                                                                              \
-        {                                                                                              \
-            rb0 = *reinterpret_cast<const float4 *>(gB + (size_t)(0) * K + (k0));                      \
-            rb1 = *reinterpret_cast<const float4 *>(gB + (size_t)(32) * K + (k0));                     \
-            rb2 = *reinterpret_cast<const float4 *>(gB + (size_t)(64) * K + (k0));                     \
-            rb3 = *reinterpret_cast<const float4 *>(gB + (size_t)(96) * K + (k0));                     \
-        }                                                                                              \
-        else if (BQ == BQ_U8)                                                                          \
-        {                                                                                              \
-            rb0 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(0) * K + (k0)), bsc, bof);   \
-            rb1 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(32) * K + (k0)), bsc, bof);  \
-            rb2 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(64) * K + (k0)), bsc, bof);  \
-            rb3 = deq_u8x4(*reinterpret_cast<const unsigned *>(gB8 + (size_t)(96) * K + (k0)), bsc, bof);  \
-        }                                                                                              \
-        else                                                                                           \
-        {                                                                                              \
-            rb0 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(0) * K + (k0)), bsc, bof);    \
-            rb1 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(32) * K + (k0)), bsc, bof);   \
-            rb2 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(64) * K + (k0)), bsc, bof);   \
-            rb3 = deq_u16x4(*reinterpret_cast<const uint2 *>(gB16 + (size_t)(96) * K + (k0)), bsc, bof);   \
-        }                                                                                              \
-        if (MODE == G_FC1)                                                                             \
-        { /* inference.cpp:78-83: x*input_scale + input_mean (F8 order), fused into the A load */      \
-            const float4 sc = *reinterpret_cast<const float4 *>(tg.q0 + (k0) + ld_kc);                 \
-            const float4 mn = *reinterpret_cast<const float4 *>(tg.q1 + (k0) + ld_kc);                 \
-            ra0 = scale_shift(ra0, sc, mn);                                                            \
-            ra1 = scale_shift(ra1, sc, mn);                                                            \
-            ra2 = scale_shift(ra2, sc, mn);                                                            \
-            ra3 = scale_shift(ra3, sc, mn);                                                            \
-        }                                                                                              \
+        UMX_GLOAD_PART(0, ra0, rb0, rq0, k0)                                                           \
+        UMX_GLOAD_PART(1, ra1, rb1, rq1, k0)                                                           \
+        UMX_GLOAD_PART(2, ra2, rb2, rq2, k0)                                                           \
+        UMX_GLOAD_PART(3, ra3, rb3, rq3, k0)                                                           \
     }
+#define UMX_FINISH_B(rbf, rbq)                                                                         \
+    (BQ == BQ_F32 ? rbf : BQ == BQ_U8 ? deq_u8x4(rbq.x, bsc, bof) : deq_u16x4(rbq, bsc, bof))
+// inference.cpp:78-83: x*input_scale + input_mean (F8 order), fused into the A staging
+#define UMX_FINISH_A(ra) (MODE == G_FC1 ? scale_shift(ra, rsc, rmn) : ra)
 #define UMX_SSTORE(buf)                                                                                \
     {                                                                                                  \
         float *a_ = sA0 + (buf)*BUF_STRIDE + ld_row * GEMM_LD + ld_kc;                                 \
         float *b_ = sB0 + (buf)*BUF_STRIDE + ld_row * GEMM_LD + ld_kc;                                 \
-        *reinterpret_cast<float4 *>(a_) = ra0;                                                         \
-        *reinterpret_cast<float4 *>(a_ + 32 * GEMM_LD) = ra1;                                          \
-        *reinterpret_cast<float4 *>(a_ + 64 * GEMM_LD) = ra2;                                          \
-        *reinterpret_cast<float4 *>(a_ + 96 * GEMM_LD) = ra3;                                          \
-        *reinterpret_cast<float4 *>(b_) = rb0;                                                         \
-        *reinterpret_cast<float4 *>(b_ + 32 * GEMM_LD) = rb1;                                          \
-        *reinterpret_cast<float4 *>(b_ + 64 * GEMM_LD) = rb2;                                          \
-        *reinterpret_cast<float4 *>(b_ + 96 * GEMM_LD) = rb3;                                          \
+        *reinterpret_cast<float4 *>(a_) = UMX_FINISH_A(ra0);                                           \
+        *reinterpret_cast<float4 *>(a_ + 32 * GEMM_LD) = UMX_FINISH_A(ra1);                            \
+        *reinterpret_cast<float4 *>(a_ + 64 * GEMM_LD) = UMX_FINISH_A(ra2);                            \
+        *reinterpret_cast<float4 *>(a_ + 96 * GEMM_LD) = UMX_FINISH_A(ra3);                            \
+        *reinterpret_cast<float4 *>(b_) = UMX_FINISH_B(rb0, rq0);                                      \
+        *reinterpret_cast<float4 *>(b_ + 32 * GEMM_LD) = UMX_FINISH_B(rb1, rq1);                       \
+        *reinterpret_cast<float4 *>(b_ + 64 * GEMM_LD) = UMX_FINISH_B(rb2, rq2);                       \
+        *reinterpret_cast<float4 *>(b_ + 96 * GEMM_LD) = UMX_FINISH_B(rb3, rq3);                       \
     }
 
     floatx16 acc00, acc01, acc10, acc11;
@@ -190,21 +196,22 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
         acc11[r] = 0.f;
     }
 
-#define UMX_COMPUTE(buf)                                                                               \
+#define UMX_COMPUTE_G(buf, g)                                                                          \
     {                                                                                                  \
         const float *a = sA0 + (buf)*BUF_STRIDE + (wm * 64 + lr) * GEMM_LD + 4 * lh;                   \
         const float *b = sB0 + (buf)*BUF_STRIDE + (wn * 64 + lr) * GEMM_LD + 4 * lh;                   \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                  \
-        {                                                                                              \
-            const float4 a0 = *reinterpret_cast<const float4 *>(a + g * 8);                            \
-            const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * GEMM_LD + g * 8);             \
-            const float4 b0 = *reinterpret_cast<const float4 *>(b + g * 8);                            \
-            const float4 b1 = *reinterpret_cast<const float4 *>(b + 32 * GEMM_LD + g * 8);             \
-            UMX_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                          \
-            UMX_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                          \
-            UMX_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                          \
-            UMX_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                          \
-        }                                                                                              \
+        const float4 a0 = *reinterpret_cast<const float4 *>(a + (g)*8);                                \
+        const float4 a1 = *reinterpret_cast<const float4 *>(a + 32 * GEMM_LD + (g)*8);                 \
+        const float4 b0 = *reinterpret_cast<const float4 *>(b + (g)*8);                                \
+        const float4 b1 = *reinterpret_cast<const float4 *>(b + 32 * GEMM_LD + (g)*8);                 \
+        UMX_MFMA4(a0.x, a1.x, b0.x, b1.x)                                                              \
+        UMX_MFMA4(a0.y, a1.y, b0.y, b1.y)                                                              \
+        UMX_MFMA4(a0.z, a1.z, b0.z, b1.z)                                                              \
+        UMX_MFMA4(a0.w, a1.w, b0.w, b1.w)                                                              \
+    }
+#define UMX_COMPUTE(buf)                                                                               \
+    {                                                                                                  \
+        UMX_COMPUTE_G(buf, 0) UMX_COMPUTE_G(buf, 1) UMX_COMPUTE_G(buf, 2) UMX_COMPUTE_G(buf, 3)       \
     }
 #define UMX_MFMA4(A0, A1, B0, B1)                                                                      \
     acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(A0, B0, acc00, 0, 0, 0);                              \
@@ -228,6 +235,10 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
 #undef UMX_GLOAD
 #undef UMX_SSTORE
 #undef UMX_COMPUTE
+#undef UMX_COMPUTE_G
+#undef UMX_GLOAD_PART
+#undef UMX_FINISH_A
+#undef UMX_FINISH_B
 #undef UMX_MFMA4
 
     // epilogue: lane owns column n, rows (r&3) + 8*(r>>2) + 4*lh of each 32x32 tile
