@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
     ap.add_argument("--serial", action="store_true", help="sync after every segment (no cross-segment pipelining)")
+    ap.add_argument("--track-seconds", type=float, default=0.0,
+                    help="also time a whole track of this length through umx_hip_shift_inference (host buffers in and "
+                         "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
     ap.add_argument("--quantised-resident", action="store_true",
                     help="BASELINE config 5: u8/u16 weights stay in HBM, dequantised in the GEMM / LSTM loads")
     args = ap.parse_args()
@@ -222,6 +225,20 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(pkg, H, wpath, args.cpu_sample_seconds)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if args.track_seconds > 0:
+            Lt = int(args.track_seconds * 44100)
+            twave = pkg.ggml.synth_audio(Lt, 99)
+            eng.separate(twave[:, :N], shift_offset=4033)  # warm-up (allocates the track buffers' first size)
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                eng.separate(twave, shift_offset=4033)
+                d = time.perf_counter() - t1
+                best = d if best is None else min(best, d)
+            line["track"] = {"seconds_of_audio": args.track_seconds, "wall_ms": round(best * 1e3, 2),
+                             "realtime_factor": round(args.track_seconds / best, 1),
+                             "segments": -(-(Lt + 22050 - 4033) // int(0.75 * N)),
+                             "includes": "pageable H2D of the track, all segments pipelined, overlap-add on device, D2H of 4 stems"}
         print(json.dumps(line), flush=True)
         if args.lstm_profile:
             pr = eng.lstm_profile()

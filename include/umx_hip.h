@@ -102,6 +102,20 @@ int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n
 int umx_hip_sync(umx_hip_ctx *ctx); /* also surfaces a persistent-kernel timeout as UMX_ERR_TIMEOUT */
 void *umx_hip_stream_handle(umx_hip_ctx *ctx); /* the hipStream_t all work is queued on */
 
+/* The whole track on the device: shift_inference (umx.cpp:99-150) around split_inference (umx.cpp:152-295).
+ * One upload of the (2,length) interleaved track, the 60 s segments (stride 0.75 * segment_samples,
+ * umx.cpp:181) queued back to back so that consecutive segments overlap in the engine's two pipeline slots,
+ * the triangular-weight overlap-add (umx.cpp:197-260) and the division by the weight sum (umx.cpp:264-273)
+ * in HBM, one download of the 4 stems.  Resets the streaming state first (umx.cpp:167-171).  Bit-identical to
+ * umx_split_inference / umx_shift_inference of umx_host.h driving umx_hip_infer_segment; sum_weight is zeroed
+ * (SURVEY F4).  offset: samples of leading silence inside the MAX_SHIFT buffer (umx.cpp:115); < 0 = the
+ * reference's unseeded rand() % 22050.  progress (may be NULL) is called once per QUEUED segment. */
+#define UMX_MAX_SHIFT 22050 /* inference.hpp:14 MAX_SHIFT_SECS * 44100 */
+int umx_hip_split_inference(umx_hip_ctx *ctx, const float *audio_host, int length, float *const out_host[4],
+                            unsigned flags, void (*progress)(float, void *), void *progress_user);
+int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int length, int offset, float *const out_host[4],
+                            unsigned flags, void (*progress)(float, void *), void *progress_user);
+
 /* One segment phase by phase: front (STFT, fc1, W_ih layer 0) | LSTM layer 0 | 1 | 2 | back (fc2, fc3, Wiener,
  * iSTFT).  Same kernels and results as umx_hip_infer_segment; the cuts are where the reference's per-chain
  * (h, c) (lstm.cpp:116-161: read at the start of a layer, left behind at its end) crosses from the GPU that ran

@@ -254,6 +254,29 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     qr.close()
 
 
+def test_device_resident_track_equals_host_split_and_shift(pkg, small):
+    """umx_hip_split_inference / umx_hip_shift_inference (track in HBM, pipelined segments, overlap-add on
+    the device) against the C++ host drivers of umx_host.h calling umx_hip_infer_segment per segment:
+    the same bits, for a multi-segment track with a ragged tail, a sub-segment track and a 1-sample track."""
+    eng, om, N = small
+    be = pkg.engine_backend(eng)
+    for L, seed in ((int(N * 3.4), 500), (N // 3, 501), (N, 502), (1, 503)):
+        wave = pkg.ggml.synth_audio(max(L, 16), seed)[:, :L]
+        host = pkg.split_inference(be, wave, N)
+        dev = eng.separate(wave)
+        for t in range(4):
+            assert (host[t] == dev[t]).all(), ("split", L, t)
+    wave = pkg.ggml.synth_audio(int(N * 2.2), 504)
+    host = pkg.shift_inference(be, wave, N, offset=4033)
+    dev = eng.separate(wave, shift_offset=4033)
+    for t in range(4):
+        assert (host[t] == dev[t]).all(), ("shift", t)
+    with pytest.raises(RuntimeError):
+        eng.separate(wave, shift_offset=22050)
+    # the per-segment API still works afterwards and starts from the state the track left
+    eng.stream_reset()
+
+
 def test_short_chunk_ragged_last_segment(pkg, po, small):
     """n < segment_samples: T stays n_buf/1024+1, the tail is zeros, outputs are (2,n) (a3, a11)."""
     eng, om, N = small

@@ -108,6 +108,9 @@ def hip_lib():
     lib.umx_hip_segment_begin.argtypes = [C.c_void_p, _fp, C.c_int, C.c_uint]
     lib.umx_hip_segment_lstm_layer.argtypes = [C.c_void_p, C.c_int]
     lib.umx_hip_segment_end.argtypes = [C.c_void_p, C.POINTER(_fp)]
+    lib.umx_hip_split_inference.argtypes = [C.c_void_p, _fp, C.c_int, C.POINTER(_fp), C.c_uint, C.c_void_p, C.c_void_p]
+    lib.umx_hip_shift_inference.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(_fp), C.c_uint, C.c_void_p,
+                                            C.c_void_p]
     _hip = lib
     return lib
 
@@ -121,7 +124,8 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_weight_bytes", "u
                "umx_hip_stage_times_slot",
                "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
-               "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end"]
+               "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
+               "umx_hip_split_inference", "umx_hip_shift_inference"]
 
 
 def views_from_file_tensors(targets, quantised=True):
@@ -236,6 +240,22 @@ class Engine:
         arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs])
         self._check(self.lib.umx_hip_segment_end(self.h, arr))
         return [np.ascontiguousarray(o.reshape(n, 2).T) for o in outs]
+
+    # --- whole track on the device (umx.cpp:99-295) ---
+    def separate(self, wave, flags=0, shift_offset=None):
+        """(2,L) host array -> 4 x (2,L): split_inference with the track resident in HBM; shift_offset: None =
+        no shift buffer, n >= 0 = shift_inference with that offset."""
+        wave = np.asarray(wave, np.float32)
+        L = wave.shape[1]
+        a = np.ascontiguousarray(wave.T).ravel()
+        outs = [np.empty(2 * L, np.float32) for _ in range(4)]
+        arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs])
+        if shift_offset is None:
+            self._check(self.lib.umx_hip_split_inference(self.h, a.ctypes.data_as(_fp), L, arr, flags, None, None))
+        else:
+            self._check(self.lib.umx_hip_shift_inference(self.h, a.ctypes.data_as(_fp), L, shift_offset, arr, flags,
+                                                         None, None))
+        return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs]
 
     # --- umx_inference (inference.cpp:12-207) ---
     def infer_segment(self, wave, flags=0):

@@ -19,6 +19,7 @@
 #include "gemm_kernels.h"
 #include "lstm_kernels.h"
 #include "lstm_wavefront.h"
+#include "track_kernels.h"
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
 
@@ -160,6 +161,12 @@ struct umx_hip_ctx
     float whh_s[3][8] = {}, whh_o[3][8] = {};
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
     // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
+    // whole track on the device (split_inference / shift_inference, umx.cpp:99-295)
+    int track(const float *audio_host, int length, int shift_offset, float *const out_host[4], unsigned flags,
+              void (*progress)(float, void *), void *progress_user);
+    float *trk_in = nullptr, *trk_out[4] = {}, *trk_sumw = nullptr, *trk_seg[2][4] = {};
+    size_t trk_cap = 0; // samples the track buffers hold
+    hipEvent_t trk_acc_ev[2] = {};
     int phase_begin(const float *audio_host, int n, unsigned flags);
     int phase_layer(int layer);
     int phase_end(float *const out_host[4]);
@@ -1229,6 +1236,115 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
     return UMX_OK;
 }
 
+// ---------------------------------------------------------------- whole track
+// shift_inference (umx.cpp:99-150) around split_inference (umx.cpp:152-295) with the track resident in HBM:
+// one upload, the segments queued back to back through the two pipeline slots (so consecutive segments
+// overlap exactly as in bench.py), the weighted overlap-add and the final normalisation on the device, one
+// download.  shift_offset < 0: no shift buffer (plain split_inference).
+int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, float *const out_host[4], unsigned flags,
+                       void (*progress)(float, void *), void *progress_user)
+{
+    if (!audio_host || !out_host || length < 1 || shift_offset >= UMX_MAX_SHIFT)
+    {
+        set_error("track: need audio, outputs, length >= 1 and shift offset < 22050");
+        return UMX_ERR_ARG;
+    }
+    if (ph_next != -1)
+    {
+        set_error("track: a phased segment is open (umx_hip_segment_end first)");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    if (int rc = sync_all())
+        return rc;
+    const int lead = shift_offset < 0 ? 0 : shift_offset;
+    const long long L2ll = shift_offset < 0 ? (long long)length : (long long)length + UMX_MAX_SHIFT - shift_offset; // umx.cpp:120-122
+    if (L2ll > 0x7fffffff / 2)
+    {
+        set_error("track: too long");
+        return UMX_ERR_ARG;
+    }
+    const int L2 = (int)L2ll;
+    if ((size_t)L2 > trk_cap) // grow-only track buffers
+    {
+        const size_t cap = (size_t)L2 + (size_t)L2 / 8;
+        for (float **p : {&trk_in, &trk_out[0], &trk_out[1], &trk_out[2], &trk_out[3], &trk_sumw})
+            if (*p)
+            {
+                allocs.erase(std::find(allocs.begin(), allocs.end(), (void *)*p));
+                (void)hipFree(*p);
+                *p = nullptr;
+            }
+        trk_cap = 0;
+        if (int rc = dalloc(&trk_in, 2 * cap, false))
+            return rc;
+        for (int t = 0; t < 4; ++t)
+            if (int rc = dalloc(&trk_out[t], 2 * cap, false))
+                return rc;
+        if (int rc = dalloc(&trk_sumw, cap, false))
+            return rc;
+        trk_cap = cap;
+    }
+    if (!trk_seg[0][0])
+    {
+        for (int s = 0; s < 2; ++s)
+        {
+            for (int t = 0; t < 4; ++t)
+                if (int rc = dalloc(&trk_seg[s][t], (size_t)2 * N, false))
+                    return rc;
+            UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
+        }
+    }
+    // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
+    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * 4 * 12 * Hl));
+    slot[0].used = slot[1].used = slot[2].used = false;
+    UMX_HIP_CHECK(hipMemset(trk_in, 0, sizeof(float) * 2 * (size_t)L2));
+    for (int t = 0; t < 4; ++t)
+        UMX_HIP_CHECK(hipMemset(trk_out[t], 0, sizeof(float) * 2 * (size_t)L2));
+    UMX_HIP_CHECK(hipMemset(trk_sumw, 0, sizeof(float) * (size_t)L2));
+    UMX_HIP_CHECK(hipMemcpy(trk_in + 2 * (size_t)lead, audio_host, sizeof(float) * 2 * (size_t)length, hipMemcpyHostToDevice));
+    UMX_HIP_CHECK(hipDeviceSynchronize());
+
+    Stems4 trk;
+    for (int t = 0; t < 4; ++t)
+        trk.p[t] = reinterpret_cast<float2 *>(trk_out[t]);
+    const int stride = (int)((1 - 0.25f) * N); // umx.cpp:181, inference.hpp:15
+    const float total_reps = std::ceil((float)L2 / (float)stride); // umx.cpp:208
+    float done = 0.f;
+    int last_slot = -1, iseg = 0;
+    for (long long off = 0; off < L2; off += stride, ++iseg)
+    {
+        const int offset = (int)off, n = std::min(N, L2 - offset); // umx.cpp:214-217
+        const bool wf = wavefront;
+        wavefront = false; // the track driver uses the two-slot pipeline
+        const int si = (int)(nseg & 1);
+        const int rc = infer_device(trk_in + 2 * (size_t)offset, n, trk_seg[si], flags);
+        wavefront = wf;
+        if (rc)
+            return rc;
+        hipStream_t st = slot[si].stream;
+        if (last_slot >= 0) // accumulate in segment order (two segments overlap by a quarter)
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, trk_acc_ev[last_slot], 0));
+        Stems4 seg;
+        for (int t = 0; t < 4; ++t)
+            seg.p[t] = reinterpret_cast<float2 *>(trk_seg[si][t]);
+        hipLaunchKernelGGL(track_accumulate_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, seg, offset, n, N);
+        UMX_HIP_CHECK(hipEventRecord(trk_acc_ev[si], st));
+        last_slot = si;
+        done += 1.0f / total_reps; // umx.cpp:229 (queued, not finished: the device runs behind the host here)
+        if (progress)
+            progress(done, progress_user);
+    }
+    hipStream_t st = slot[last_slot].stream;
+    hipLaunchKernelGGL(track_normalise_kernel, dim3((L2 + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, L2);
+    UMX_HIP_CHECK(hipGetLastError());
+    if (int rc = umx_hip_sync(this))
+        return rc;
+    for (int t = 0; t < 4; ++t) // umx.cpp:136-147: drop the shift
+        UMX_HIP_CHECK(hipMemcpy(out_host[t], trk_out[t] + 2 * (size_t)lead, sizeof(float) * 2 * (size_t)length, hipMemcpyDeviceToHost));
+    return UMX_OK;
+}
+
 // ---------------------------------------------------------------- one segment, phase by phase
 // The same launches as infer_device on slot 0, cut where another GPU's LSTM state has to come in: the
 // caller sets layer l's incoming (h, c) (umx_hip_stream_set_layer) before phase_layer(l) and reads the
@@ -1464,6 +1580,21 @@ int umx_hip_stream_get_layer(umx_hip_ctx *ctx, int layer, float *host_dst) { ret
 int umx_hip_stream_set_layer(umx_hip_ctx *ctx, int layer, const float *host_src)
 {
     return stream_layer_copy(ctx, layer, const_cast<float *>(host_src), false);
+}
+
+int umx_hip_split_inference(umx_hip_ctx *ctx, const float *audio_host, int length, float *const out_host[4],
+                            unsigned flags, void (*progress)(float, void *), void *progress_user)
+{
+    return ctx ? ctx->track(audio_host, length, -1, out_host, flags, progress, progress_user) : UMX_ERR_ARG;
+}
+int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int length, int offset, float *const out_host[4],
+                            unsigned flags, void (*progress)(float, void *), void *progress_user)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    if (offset < 0)
+        offset = rand() % UMX_MAX_SHIFT; // umx.cpp:115 (never seeded in the reference)
+    return ctx->track(audio_host, length, offset, out_host, flags, progress, progress_user);
 }
 
 int umx_hip_segment_begin(umx_hip_ctx *ctx, const float *audio_host, int n, unsigned flags)

@@ -1,9 +1,11 @@
 // umx_cli.cpp -- `umx-cli <model file> <wav file> <out dir>`: the reference's CLI (umx.cpp:26-97)
 // over the MI355X engine.  Loads the wav, loads the ggml weight file, creates the device context,
-// runs shift_inference -> split_inference -> per-segment umx_hip_infer_segment, writes
+// runs shift_inference -> split_inference on the device (umx_hip_shift_inference: track resident in HBM,
+// segments pipelined; UMX_CLI_PER_SEGMENT=1 selects the host drivers over umx_hip_infer_segment), writes
 // target_{0..3}.wav (0 = bass, 1 = drums, 2 = other, 3 = vocals).  Exit code 1 on any failure,
 // like the reference.  Extra knobs come from the environment only, so the 3 positionals stay:
-//   UMX_DEVICE=<n>   UMX_NO_WIENER=1   UMX_SHIFT_OFFSET=<n>   UMX_LSTM_STEPWISE=1
+//   UMX_DEVICE=<n>   UMX_NO_WIENER=1   UMX_SHIFT_OFFSET=<n>   UMX_LSTM_STEPWISE=1   UMX_CLI_PER_SEGMENT=1
+//   UMX_WEIGHTS_RESIDENT=quantised
 #include "../../include/umx_host.h"
 
 #include <chrono>
@@ -91,16 +93,26 @@ int main(int argc, const char **argv)
         out[t] = stems[t].data();
     }
     const auto t2 = std::chrono::steady_clock::now();
-    if (umx_shift_inference(&be, audio, n, UMX_SEGMENT_SAMPLES, env_int("UMX_SHIFT_OFFSET", -1), out,
-                            print_progress, nullptr, err)) // umx.cpp:72-73
+    const bool per_segment = env_int("UMX_CLI_PER_SEGMENT", 0) != 0;
+    if (per_segment)
     {
-        fprintf(stderr, "inference failed: %s\n", err);
+        if (umx_shift_inference(&be, audio, n, UMX_SEGMENT_SAMPLES, env_int("UMX_SHIFT_OFFSET", -1), out,
+                                print_progress, nullptr, err)) // umx.cpp:72-73
+        {
+            fprintf(stderr, "inference failed: %s\n", err);
+            return 1;
+        }
+    }
+    else if (umx_hip_shift_inference(ctx, audio, n, env_int("UMX_SHIFT_OFFSET", -1), out, hb.flags, print_progress,
+                                     nullptr)) // umx.cpp:72-73
+    {
+        fprintf(stderr, "inference failed: %s\n", umx_hip_last_error(ctx));
         return 1;
     }
     const auto t3 = std::chrono::steady_clock::now();
     const double secs = std::chrono::duration<double>(t3 - t2).count();
-    printf("Separated %.2f s of audio in %.3f s (%.1fx realtime, host buffers in/out)\n", n / 44100.0, secs,
-           n / 44100.0 / secs);
+    printf("Separated %.2f s of audio in %.3f s (%.1fx realtime, host buffers in/out, %s)\n", n / 44100.0, secs,
+           n / 44100.0 / secs, per_segment ? "one segment at a time" : "track resident in HBM");
 
     std::error_code ec;
     std::filesystem::create_directories(out_dir, ec); // umx.cpp:84-86
