@@ -228,13 +228,10 @@ def main():
         if args.track_seconds > 0:
             Lt = int(args.track_seconds * 44100)
             twave = pkg.ggml.synth_audio(Lt, 99)
-            eng.separate(twave[:, :N], shift_offset=4033)  # warm-up (allocates the track buffers' first size)
-            best = None
-            for _ in range(3):
-                t1 = time.perf_counter()
-                eng.separate(twave, shift_offset=4033)
-                d = time.perf_counter() - t1
-                best = d if best is None else min(best, d)
+            ta = np.ascontiguousarray(twave.T).ravel()
+            touts = [np.empty(2 * Lt, np.float32) for _ in range(4)]
+            eng.separate_interleaved(ta, Lt, touts, shift_offset=4033)  # warm-up: allocates the track buffers
+            best = min(eng.separate_interleaved(ta, Lt, touts, shift_offset=4033) for _ in range(3))
             line["track"] = {"seconds_of_audio": args.track_seconds, "wall_ms": round(best * 1e3, 2),
                              "realtime_factor": round(args.track_seconds / best, 1),
                              "segments": -(-(Lt + 22050 - 4033) // int(0.75 * N)),

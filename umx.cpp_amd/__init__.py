@@ -249,13 +249,21 @@ class Engine:
         L = wave.shape[1]
         a = np.ascontiguousarray(wave.T).ravel()
         outs = [np.empty(2 * L, np.float32) for _ in range(4)]
-        arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs])
-        if shift_offset is None:
-            self._check(self.lib.umx_hip_split_inference(self.h, a.ctypes.data_as(_fp), L, arr, flags, None, None))
-        else:
-            self._check(self.lib.umx_hip_shift_inference(self.h, a.ctypes.data_as(_fp), L, shift_offset, arr, flags,
-                                                         None, None))
+        self.separate_interleaved(a, L, outs, flags, shift_offset)
         return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs]
+
+    def separate_interleaved(self, a, L, outs, flags=0, shift_offset=None):
+        """The bare C call: a = (2,L) interleaved float32, outs = 4 preallocated float32[2L]; returns seconds."""
+        import time
+        arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs])
+        t0 = time.perf_counter()
+        if shift_offset is None:
+            rc = self.lib.umx_hip_split_inference(self.h, a.ctypes.data_as(_fp), L, arr, flags, None, None)
+        else:
+            rc = self.lib.umx_hip_shift_inference(self.h, a.ctypes.data_as(_fp), L, shift_offset, arr, flags, None, None)
+        dt = time.perf_counter() - t0
+        self._check(rc)
+        return dt
 
     # --- umx_inference (inference.cpp:12-207) ---
     def infer_segment(self, wave, flags=0):

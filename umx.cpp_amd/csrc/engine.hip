@@ -5,6 +5,7 @@
 // The four targets run inside the same launches; consecutive segments alternate between two pipeline
 // slots (streams) so that their LSTM layers overlap as an exact wavefront (see struct Slot).
 #include "../../include/umx_hip.h"
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -1295,6 +1296,8 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
             UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
         }
     }
+    const bool timing = getenv("UMX_TRACK_TIMING") != nullptr;
+    const auto tt0 = std::chrono::steady_clock::now();
     // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
     UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * 4 * 12 * Hl));
     slot[0].used = slot[1].used = slot[2].used = false;
@@ -1305,6 +1308,7 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     UMX_HIP_CHECK(hipMemcpy(trk_in + 2 * (size_t)lead, audio_host, sizeof(float) * 2 * (size_t)length, hipMemcpyHostToDevice));
     UMX_HIP_CHECK(hipDeviceSynchronize());
 
+    const auto tt1 = std::chrono::steady_clock::now();
     Stems4 trk;
     for (int t = 0; t < 4; ++t)
         trk.p[t] = reinterpret_cast<float2 *>(trk_out[t]);
@@ -1340,8 +1344,16 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     UMX_HIP_CHECK(hipGetLastError());
     if (int rc = umx_hip_sync(this))
         return rc;
+    const auto tt2 = std::chrono::steady_clock::now();
     for (int t = 0; t < 4; ++t) // umx.cpp:136-147: drop the shift
         UMX_HIP_CHECK(hipMemcpy(out_host[t], trk_out[t] + 2 * (size_t)lead, sizeof(float) * 2 * (size_t)length, hipMemcpyDeviceToHost));
+    if (timing)
+    {
+        const auto tt3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[umx track] %d samples: clear+upload %.1f ms, %d segments %.1f ms, download %.1f ms\n", length,
+                ms(tt0, tt1), iseg, ms(tt1, tt2), ms(tt2, tt3));
+    }
     return UMX_OK;
 }
 
