@@ -274,6 +274,10 @@ constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then 
 #ifndef LSTM_PROF_WAVE
 #define LSTM_PROF_WAVE 1 // the dot wave the in-kernel profiler reports beside the gate wave
 #endif
+#ifndef LSTM_P_BULK
+#define LSTM_P_BULK 16 // W_ih x + b_ih rows fetched per bulk (multiple of 8, power of two)
+#endif
+#define LSTM_P_RING (2 * LSTM_P_BULK)
 #ifndef LSTM_GATE_PRIO
 #define LSTM_GATE_PRIO 1 // s_setprio of the gate wave during its serial gate phase (measured: -1.5 % per segment pipelined)
 #endif
@@ -480,18 +484,31 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     const unsigned tag_base = a.tag_base;
     const int S = a.S;
     float hlast = 0.f;
-    // W_ih x + b_ih rows come from HBM (~750 cycles) and vmcnt retires in order, so a load issued by the gate
-    // wave would hold its next poll -- the chain's critical path -- for the HBM latency.  Wave 7 (which
-    // idles at the barrier anyway) fetches row t+2 right before barrier t and parks row t+1 in LDS; the gate
-    // wave reads its row from LDS together with the partial sums.  Four slots: row t+1 is written while
-    // row t-1 may still be read.
-    const bool p_wave = (w == 7);
-    float preg = 0.f;
-    if (p_wave)
+    // W_ih x + b_ih rows come from HBM, and vmcnt retires in order: whichever wave has such a load in flight
+    // cannot complete its next hidden-state poll before the row has arrived.  Alone on the chip that is ~750
+    // cycles; beside a GEMM or a streaming kernel of the other pipeline slot it is several microseconds, and a
+    // row fetched every step put exactly that in front of every step (an LSTM launch sharing the chip with a
+    // copy kernel ran 3x slower).  So rows are fetched in bulk, LSTM_P_BULK at a time and LSTM_P_BULK..2x steps
+    // ahead, straight into an LDS ring (global_load_lds: no VGPRs, no ds_write), two rows per dot wave: the
+    // loaded-latency is paid once per LSTM_P_BULK steps instead of once per step.
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+    const unsigned pbuf_lds = (unsigned)(size_t)(lds_ptr)&pbuf[0][0]; // LDS byte address of the ring
+    auto fetch_rows = [&](int first_row) { // this wave's share (rows first_row + 2w, + 2w + 1) of a bulk
+#pragma unroll
+        for (int j = 0; j < LSTM_P_BULK / 8; ++j)
+        {
+            const int r = first_row + w * (LSTM_P_BULK / 8) + j;
+            if (r < T)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(Pp + (size_t)(dir == 0 ? r : T - 1 - r) * ldp),
+                                                 (lds_ptr)(size_t)(pbuf_lds + 256u * (unsigned)(r & (LSTM_P_RING - 1))), 4, 0, 0);
+        }
+    };
+    if (dot_wave)
     {
-        pbuf[0][l] = Pp[(size_t)(dir == 0 ? 0 : T - 1) * ldp];
-        if (T > 1)
-            preg = Pp[(size_t)(dir == 0 ? 1 : T - 2) * ldp];
+        fetch_rows(0);
+        fetch_rows(LSTM_P_BULK);
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the rows are in LDS before the first barrier
     }
     const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == gw || w == LSTM_PROF_WAVE); // wave-uniform
     unsigned long long pc[5] = {0, 0, 0, 0, 0};
@@ -555,6 +572,11 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                         __builtin_amdgcn_s_sleep(1);
                 }
                 hval = __uint_as_float((unsigned)x);
+                // rows [step + BULK, step + 2 BULK) replace rows [step - BULK, step), all consumed: every slice
+                // has published step - 1.  They land in LDS before this wave's next poll completes (vmcnt in
+                // order) and are first read BULK barriers later.
+                if ((step & (LSTM_P_BULK - 1)) == 0)
+                    fetch_rows(step + LSTM_P_BULK);
             }
             if (prof)
                 c1 = clock64();
@@ -596,13 +618,6 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 (*(part + (step & 1)))[w][l] = acc.x + acc.y;
             }
         }
-        if (p_wave)
-        {
-            pbuf[(step + 1) & 3][l] = preg; // row step+1, loaded one step ago
-            asm volatile("" ::: "memory");
-            if (step + 2 < T)
-                preg = Pp[(size_t)(dir == 0 ? step + 2 : T - 3 - step) * ldp];
-        }
         if (prof)
             c2 = clock64();
         __syncthreads();
@@ -617,7 +632,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
 #endif
             float(*pq)[64] = *(part + (step & 1));
             const float s = ((pq[0][l] + pq[1][l]) + (pq[2][l] + pq[3][l])) + ((pq[4][l] + pq[5][l]) + (pq[6][l] + pq[7][l]));
-            const float pre = (pbuf[step & 3][l] + s) + bh;
+            const float pre = (pbuf[step & (LSTM_P_RING - 1)][l] + s) + bh;
             float h;
             lstm_cell<PRECISE>(pre, l, c, h);
             if ((l & 3) == 0)
@@ -657,7 +672,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
 template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_THREADS) void lstm_persistent_kernel(LstmArgs a)
 {
     __shared__ float part[2][8][64];
-    __shared__ float pbuf[4][64]; // W_ih x + b_ih rows of steps t .. t+1 (see lstm_persistent_body)
+    __shared__ float pbuf[LSTM_P_RING][64]; // ring of W_ih x + b_ih rows (see lstm_persistent_body)
     __shared__ int s_ctl[4]; // chain, slice, fast, abort
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, S = a.S;
