@@ -246,13 +246,13 @@ def main():
                         c = pp[layer, w]
                         n = max(int(c[4]), 1)
                         print(f"# pipelined lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
-                              f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} (steps {int(c[4])})", file=sys.stderr)
+                              f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])})", file=sys.stderr)
             for layer in range(3):
                 for w in range(2):
                     c = pr[layer, w]
                     n = max(int(c[4]), 1)
                     print(f"# lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
-                          f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} (steps {int(c[4])})", file=sys.stderr)
+                          f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])})", file=sys.stderr)
     eng.close()
     if world > 1:
         dist.barrier()

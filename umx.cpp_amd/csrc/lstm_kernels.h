@@ -511,7 +511,8 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the rows are in LDS before the first barrier
     }
     const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == gw || w == LSTM_PROF_WAVE); // wave-uniform
-    unsigned long long pc[5] = {0, 0, 0, 0, 0};
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned prof_spins = 0;
 
     for (int step = 0; step < T; ++step)
     {
@@ -571,6 +572,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                     if (!FAST)
                         __builtin_amdgcn_s_sleep(1);
                 }
+                prof_spins = spins;
                 hval = __uint_as_float((unsigned)x);
                 // rows [step + BULK, step + 2 BULK) replace rows [step - BULK, step), all consumed: every slice
                 // has published step - 1.  They land in LDS before this wave's next poll completes (vmcnt in
@@ -655,6 +657,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             pc[2] += (unsigned long long)(c3 - c2); // barrier wait
             pc[3] += (unsigned long long)(c4 - c3); // gates + publish (gate wave)
             pc[4] += 1;
+            pc[5] += prof_spins; // failed polls
         }
     }
     if (gate_wave && (l & 3) == 0) // lstm.cpp:160-161: the state carries into the next segment
@@ -663,7 +666,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         a.state[state_off(target, a.layer, dir, 1, Hl) + unit] = c;
     }
     if (prof && l == 0)
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 6; ++i)
             a.prof[(a.layer * 2 + (w == gw ? 0 : 1)) * 8 + i] = pc[i];
 }
 
