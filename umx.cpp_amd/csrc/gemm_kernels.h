@@ -54,12 +54,12 @@ struct GemmArgs
     int M, N, K, lda, ldc, T;
 };
 
-// Which modes pin the next tile's global loads at the top of the K tile (see UMX_GLOAD_PART).  fc1 gains 20 %
-// (its K loop is long and its A prologue loads two extra vectors); for the other modes two blocks per CU
-// already hide the latency and the longer live ranges would push them past the 152-VGPR budget of the
-// two-slot pipeline (see below), so they keep the compiler's order.
+// Knob: pin the next tile's global loads at the top of the K tile with sched_barrier (consumers are deferred
+// to the LDS store either way).  Measured with flat global loads it helped fc1 only (0.95 -> 0.75 ms) and cost
+// 20-30 VGPRs elsewhere; with buffer loads (below) the compiler's own order is best everywhere
+// (fc1 0.65 ms), so the default pins nothing.
 #ifndef GEMM_PIN_LOADS
-#define GEMM_PIN_LOADS(MODE) ((MODE) == G_FC1)
+#define GEMM_PIN_LOADS(MODE) 0
 #endif
 #ifndef GEMM_SWIZZLE
 #define GEMM_SWIZZLE 1
@@ -127,12 +127,17 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
     float *const sA0 = smem, *const sB0 = smem + 128 * GEMM_LD;
     constexpr int BUF_STRIDE = 2 * 128 * GEMM_LD;
 
-    // global -> register staging: 4 float4 of A and 4 of B per thread per K tile
+    // global -> register staging: 4 float4 of A and 4 of B per thread per K tile, as buffer loads: one
+    // resource per operand, ONE constant 32-bit per-thread offset (voffset) and a wave-uniform scalar offset
+    // (soffset: tile origin + row group + k) -- 2 address VGPRs and no 64-bit vector address arithmetic in the
+    // K loop (flat global addressing cost 16-20 VGPRs and pushed the pinned-load variants past the budget).
     const int ld_row = tid >> 3, ld_kc = (tid & 7) * 4;
-    const float *gA = tg.A + (size_t)(m0 + ld_row) * lda + ld_kc;
-    const float *gB = tg.B + (size_t)(n0 + ld_row) * K + ld_kc;
-    const unsigned char *gB8 = static_cast<const unsigned char *>(tg.Bq) + (size_t)(n0 + ld_row) * K + ld_kc;
-    const unsigned short *gB16 = static_cast<const unsigned short *>(tg.Bq) + (size_t)(n0 + ld_row) * K + ld_kc;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tg.A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        BQ == BQ_F32 ? (void *)const_cast<float *>(tg.B) : const_cast<void *>(tg.Bq), 0, 0x7fffffff, 0x00020000);
+    constexpr int BEL = BQ == BQ_F32 ? 4 : BQ == BQ_U8 ? 1 : 2; // bytes per B element as resident
+    const int voffA = (ld_row * lda + ld_kc) * 4, voffB = (ld_row * K + ld_kc) * BEL;
+    const int soffA0 = m0 * lda * 4, soffB0 = n0 * K * BEL;
     const float bsc = tg.bs[n0 >= tg.bsplit ? 1 : 0], bof = tg.bo[n0 >= tg.bsplit ? 1 : 0]; // block-uniform
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3, rsc, rmn;
     uint2 rq0, rq1, rq2, rq3;
@@ -144,19 +149,20 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
 // MFMAs later, and __builtin_amdgcn_sched_barrier pins the loads where they are written -- left alone, the
 // scheduler sinks them to the end of the tile (right before the LDS stores) and every K tile then waits
 // out a full memory latency.
+#define UMX_AS_F4(v) __builtin_bit_cast(float4, v)
 #define UMX_GLOAD_PART(j, ra, rbf, rbq, k0)                                                            \
     {                                                                                                  \
-        ra = *reinterpret_cast<const float4 *>(gA + (size_t)(32 * (j)) * lda + (k0));                  \
+        ra = UMX_AS_F4(__builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, soffA0 + (32 * (j) * lda + (k0)) * 4, 0));  \
         if (BQ == BQ_F32)                                                                              \
-            rbf = *reinterpret_cast<const float4 *>(gB + (size_t)(32 * (j)) * K + (k0));               \
+            rbf = UMX_AS_F4(__builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, soffB0 + (32 * (j) * K + (k0)) * 4, 0)); \
         else if (BQ == BQ_U8)                                                                          \
-            rbq.x = *reinterpret_cast<const unsigned *>(gB8 + (size_t)(32 * (j)) * K + (k0));          \
+            rbq.x = __builtin_amdgcn_raw_buffer_load_b32(rsB, voffB, soffB0 + (32 * (j) * K + (k0)), 0);   \
         else                                                                                           \
-            rbq = *reinterpret_cast<const uint2 *>(gB16 + (size_t)(32 * (j)) * K + (k0));              \
+            rbq = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsB, voffB, soffB0 + (32 * (j) * K + (k0)) * 2, 0)); \
         if (MODE == G_FC1 && (j) == 0)                                                                 \
         {                                                                                              \
-            rsc = *reinterpret_cast<const float4 *>(tg.q0 + (k0) + ld_kc);                             \
-            rmn = *reinterpret_cast<const float4 *>(tg.q1 + (k0) + ld_kc);                             \
+            rsc = *reinterpret_cast<const float4 *>((tg.q0 + (k0)) + (unsigned)ld_kc);                 \
+            rmn = *reinterpret_cast<const float4 *>((tg.q1 + (k0)) + (unsigned)ld_kc);                 \
         }                                                                                              \
         if (GEMM_PIN_LOADS(MODE))                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -237,6 +243,7 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
 #undef UMX_COMPUTE
 #undef UMX_COMPUTE_G
 #undef UMX_GLOAD_PART
+#undef UMX_AS_F4
 #undef UMX_FINISH_A
 #undef UMX_FINISH_B
 #undef UMX_MFMA4
