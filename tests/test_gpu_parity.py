@@ -64,6 +64,15 @@ def test_stage_parity_umxl_hidden_64_frames():
     _check_report(rep)
 
 
+@pytest.mark.parametrize("hidden", [256, 512])
+def test_stage_parity_other_hidden_sizes(hidden):
+    """hidden=512 is the reference's umxhq / umx models (model.cpp:109-114 reads the size from the file);
+    256 exercises the remaining LSTM register layout (16 weights per lane)."""
+    rep = stagecheck.stage_report(hidden, 32 * 1024, segments=2, verbose=False)
+    assert rep[0]["persistent"] is True
+    _check_report(rep)
+
+
 def test_persistent_and_stepwise_lstm_are_bitwise_identical(pkg, small):
     eng, _, N = small
     wave = pkg.ggml.synth_audio(N, 21)

@@ -1493,6 +1493,9 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
     for (int i = 0; i < 3; ++i)
         if (ctx->lstm_ev[i])
             (void)hipEventDestroy(ctx->lstm_ev[i]);
+    for (hipEvent_t e : ctx->trk_acc_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     for (int si = 0; si < 3; ++si)
     {
         Slot &sl = ctx->slot[si];
