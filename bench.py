@@ -74,8 +74,8 @@ def cpu_baseline(pkg, hidden, weights_path, seconds_audio=6.0, threads=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--segment-samples", type=int, default=SEG)
     ap.add_argument("--no-wiener", action="store_true")
