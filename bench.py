@@ -119,13 +119,17 @@ def main():
 
     wave = pkg.ggml.synth_audio(N, seed=rank)  # each rank: its own track
     audio = torch.from_numpy(np.ascontiguousarray(wave.T).ravel()).to(dev)  # (2,n) interleaved, in HBM
-    outs = [torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)]
+    # two output sets: consecutive segments are in flight together (two pipeline slots) and must not share stems
+    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)] for _ in range(2)]
+    outs = out_sets[0]
     flags = (pkg.FLAG_NO_WIENER if args.no_wiener else 0) | (pkg.FLAG_LSTM_STEPWISE if args.stepwise_lstm else 0) | \
         (pkg.FLAG_LSTM_FORCE_SAFE if args.safe_lstm else 0) | (pkg.FLAG_LSTM_PROFILE if args.lstm_profile else 0)
-    ptrs = [o.data_ptr() for o in outs]
+    ptr_sets = [[o.data_ptr() for o in st_] for st_ in out_sets]
+    nstep = [0]
 
     def step():
-        eng.infer_segment_device(audio.data_ptr(), N, ptrs, flags)
+        eng.infer_segment_device(audio.data_ptr(), N, ptr_sets[nstep[0] & 1], flags)
+        nstep[0] += 1
         if args.serial:
             eng.sync()
 
@@ -153,7 +157,7 @@ def main():
         serial.append((time.perf_counter() - t1) * 1e3)
         stage_alone_ms = eng.stage_times()
     serial_ms = min(serial)
-    finite = bool(all(torch.isfinite(o).all().item() for o in outs))
+    finite = bool(all(torch.isfinite(o).all().item() for st_ in out_sets for o in st_))
 
     if rank == 0:
         seg_sec = N / 44100.0
