@@ -88,8 +88,11 @@ def main():
     ap.add_argument("--track-seconds", type=float, default=0.0,
                     help="also time a whole track of this length through umx_hip_shift_inference (host buffers in and "
                          "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
-    ap.add_argument("--quantised-resident", action="store_true",
-                    help="BASELINE config 5: u8/u16 weights stay in HBM, dequantised in the GEMM / LSTM loads")
+    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=None,
+                    help="dense-stack GEMM flavour: bf16x3 (default; three-term bf16 split, fp32-class accuracy) or f32 MFMA")
+    ap.add_argument("--expanded-weights", action="store_true",
+                    help="expand the u8/u16 weights at load time (fp32 / three bf16 planes in HBM) instead of keeping "
+                         "them quantised in HBM with dequantisation inside the kernels (the default, BASELINE config 5)")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +117,8 @@ def main():
     tmpdir = tempfile.mkdtemp(prefix=f"umx_bench_r{rank}_")
     wpath = os.path.join(tmpdir, "ggml-model-synth-u8.bin")
     pkg.ggml.write_model(wpath, pkg.ggml.synth_weights(H, seed=0), H, compress=False)
-    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=args.quantised_resident)
+    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=not args.expanded_weights,
+                               gemm=args.gemm)
     T = eng.T
 
     wave = pkg.ggml.synth_audio(N, seed=rank)  # each rank: its own track
@@ -213,7 +217,11 @@ def main():
                        "hidden": H, "segment_samples": N, "frames": T, "stems": 4,
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(
                            eng.lstm_mode(), "?"),
-                       "weights_resident": "u8/u16 (dequantised in the kernels)" if args.quantised_resident else "f32",
+                       "gemm": ((args.gemm or os.environ.get("UMX_GEMM", "bf16x3")) +
+                                (" (fp32 operands split into 3 bf16 terms, 6 products, f32 accumulate: error below fp32 rounding)"
+                                 if (args.gemm or os.environ.get("UMX_GEMM", "bf16x3")) == "bf16x3" else " MFMA")),
+                       "weights_resident": ("expanded at load (f32 / bf16 planes)" if args.expanded_weights
+                                            else "u8/u16 as in the file (dequantised in the kernels)"),
                        "weight_bytes": eng.weight_bytes(),
                        "sharding": f"{world} independent segments (one per rank)"},
             "roofline": roofline,

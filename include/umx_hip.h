@@ -69,13 +69,22 @@ typedef struct umx_hip_ctx umx_hip_ctx;
  * Needs 4 x 43 tensors (model.cpp:240-539 name dispatch).  hidden_size % 128 == 0. */
 int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                    const umx_tensor_view *tensors, int n_tensors);
-/* BASELINE config 5 / SURVEY 8(f)1: keep the matrices as stored in the ggml file (u8: fc1, W_ih, W_hh; u16: fc2,
- * fc3 -- convert-umx-pth-to-ggml.py:127-160) resident in HBM and dequantise q*scale+offset (model.cpp:610-616)
- * where they are consumed: in the GEMM's B-tile staging and in the LSTM kernel's one-time W_hh register load.
- * Results are bit-identical to umx_hip_create on the same views; HBM held by weights drops from 452 MB to
- * ~139 MB for UMX-L (umx_hip_weight_bytes).  Tensors handed over as fp32 views stay fp32.
- * umx_hip_create honours the environment variable UMX_WEIGHTS_RESIDENT=quantised as the same switch. */
+/* Weight residency (BASELINE config 5 / SURVEY 8(f)1).  Tensors handed over as u8 / u16 views (the ggml file's own
+ * bytes: u8 fc1, W_ih, W_hh; u16 fc2, fc3 -- convert-umx-pth-to-ggml.py:127-160) stay that way in HBM by default
+ * and q*scale+offset (model.cpp:610-616) is evaluated where they are consumed: in the GEMM's B-tile staging and in
+ * the LSTM kernel's one-time W_hh register load.  139 MB of weights for UMX-L instead of 452 MB (fp32) / 630 MB
+ * (three bf16 planes), bit-identical results, and measured FASTER (7.5 vs 8.0 ms per segment: the B operand moves
+ * 1-2 bytes per weight instead of 6).  UMX_CREATE_DEQUANTISE_AT_LOAD (environment UMX_WEIGHTS_RESIDENT=expanded)
+ * expands them at load time instead; fp32 views are always expanded.  UMX_CREATE_QUANTISED_RESIDENT is accepted
+ * for compatibility and is the default. */
 #define UMX_CREATE_QUANTISED_RESIDENT 0x1u
+#define UMX_CREATE_DEQUANTISE_AT_LOAD 0x8u
+/* The dense stack (fc1, W_ih, fc2, fc3 -- inference.cpp:86,127,143, lstm.cpp:132-135) runs by default on the bf16
+ * matrix cores with every fp32 operand split into three bf16 terms and six products kept: the dropped terms are
+ * below 2^-26 of the product, and against a float64 evaluation the result is as close as (measured: slightly
+ * closer than) the fp32-MFMA kernel's, at 2.7x less matrix-core time (csrc/gemm_bf16x3.h, tools/gemm_accuracy.py).
+ * UMX_CREATE_GEMM_F32 (environment UMX_GEMM=f32) selects the fp32-MFMA kernels (exact fp32 FMA chain) instead. */
+#define UMX_CREATE_GEMM_F32 0x4u
 int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx); /* HBM bytes held by the model's weight matrices */

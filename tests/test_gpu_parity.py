@@ -131,8 +131,8 @@ def test_pipelined_segments_equal_one_at_a_time(pkg, tmp_path):
     results = {}
     for mode in ("wavefront", "slots"):
         os.environ["UMX_PIPELINE"] = mode
-        try:
-            eng = pkg.Engine.from_file(path, N)
+        try:  # (the fused-launch experiment only knows expanded fp32 W_hh)
+            eng = pkg.Engine.from_file(path, N, quantised_resident=(mode != "wavefront"))
         finally:
             os.environ.pop("UMX_PIPELINE", None)
         # (a) one at a time (host API syncs after every segment)
@@ -233,9 +233,9 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     path, om, targets = model_small
     N = 16 * 1024
     waves = [pkg.ggml.synth_audio(N, 400 + i) for i in range(2)]
-    ref = pkg.Engine(targets, 128, N)
-    qr = pkg.Engine(targets, 128, N, quantised_resident=True)
-    assert qr.weight_bytes() * 2.5 < ref.weight_bytes()
+    ref = pkg.Engine(targets, 128, N, quantised_resident=False)
+    qr = pkg.Engine(targets, 128, N)  # the default
+    assert qr.weight_bytes() * 3.5 < ref.weight_bytes()  # u8/u16 against three bf16 planes (+ fp32 W_hh)
     for flags in (0, pkg.FLAG_LSTM_STEPWISE):
         ref.stream_reset()
         qr.stream_reset()
@@ -245,15 +245,24 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
                 assert (a[t] == b[t]).all(), (flags, t)
         assert (ref.stream_get() == qr.stream_get()).all()
     # fp32 views cannot stay quantised: the flag is then a no-op, not an error
-    f32 = pkg.Engine(targets, 128, N, quantised=False, quantised_resident=True)
+    f32 = pkg.Engine(targets, 128, N, quantised=False)
     assert f32.weight_bytes() == ref.weight_bytes()
     for e in (ref, qr, f32):
         e.close()
     H, N = 1024, 24 * 1024
     p = str(tmp_path / "m.bin")
     pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=31), H, compress=False)
-    ref, qr = pkg.Engine.from_file(p, N), pkg.Engine.from_file(p, N, quantised_resident=True)
-    assert 130e6 < qr.weight_bytes() < 150e6 and 440e6 < ref.weight_bytes() < 470e6
+    ref, qr = pkg.Engine.from_file(p, N, quantised_resident=False), pkg.Engine.from_file(p, N)
+    assert 130e6 < qr.weight_bytes() < 150e6 and 600e6 < ref.weight_bytes() < 640e6
+    f32 = pkg.Engine.from_file(p, N, gemm="f32", quantised_resident=False)
+    assert 440e6 < f32.weight_bytes() < 470e6
+    f32q = pkg.Engine.from_file(p, N, gemm="f32")
+    wv = pkg.ggml.synth_audio(N, 411)
+    a32, b32 = f32.infer_segment(wv), f32q.infer_segment(wv)
+    for t in range(4):
+        assert (a32[t] == b32[t]).all()
+    f32.close()
+    f32q.close()
     w = pkg.ggml.synth_audio(N, 410)
     a, b = ref.infer_segment(w), qr.infer_segment(w)
     assert qr.lstm_mode() == 2
@@ -284,6 +293,52 @@ def test_device_resident_track_equals_host_split_and_shift(pkg, small):
         eng.separate(wave, shift_offset=22050)
     # the per-segment API still works afterwards and starts from the state the track left
     eng.stream_reset()
+
+
+def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_path):
+    """The dense stack runs on the bf16 matrix cores by default (fp32 operands split into three bf16 terms, six
+    products, fp32 accumulation: csrc/gemm_bf16x3.h); gemm="f32" keeps the fp32-MFMA kernels.  Both must sit within
+    the same distance of the oracle, agree with each other to fp32 rounding, and -- for either flavour -- queuing
+    segments back to back must give the bits of one segment at a time (co-residency of bf16 MFMA waves with other
+    kernels' waves is what this guards)."""
+    import torch
+    torch.zeros(1).cuda()
+    path, om, targets = model_small
+    N = 16 * 1024
+    waves = [pkg.ggml.synth_audio(N, 600 + i) for i in range(2)]
+    state = po.stream_state(128)
+    ref = [po.umx_inference(om, w, n_buf=N, state=state)[0] for w in waves]
+    outs = {}
+    for gemm in ("bf16x3", "f32"):
+        eng = pkg.Engine(targets, 128, N, gemm=gemm)
+        outs[gemm] = [eng.infer_segment(w) for w in waves]
+        eng.close()
+        for i in range(2):
+            for t in range(4):
+                assert np.abs(outs[gemm][i][t] - ref[i][t]).max() < TOL_WAVE
+    for i in range(2):
+        for t in range(4):
+            assert np.abs(outs["bf16x3"][i][t] - outs["f32"][i][t]).max() < 1e-5
+    # UMX-L width, pipelined == serial, both flavours
+    H, N, NSEG = 1024, 40 * 1024, 6
+    p = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=33), H, compress=False)
+    waves = [pkg.ggml.synth_audio(N, 610 + i) for i in range(NSEG)]
+    ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda() for w in waves]
+    for gemm in ("bf16x3", "f32"):
+        eng = pkg.Engine.from_file(p, N, gemm=gemm)
+        eng.stream_reset()
+        serial = [eng.infer_segment(w) for w in waves]
+        eng.stream_reset()
+        o = [[torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)] for _ in range(NSEG)]
+        torch.cuda.synchronize()
+        for i in range(NSEG):
+            eng.infer_segment_device(ins[i].data_ptr(), N, [x.data_ptr() for x in o[i]])
+        eng.sync()
+        for i in range(NSEG):
+            for t in range(4):
+                assert (o[i][t].cpu().numpy().reshape(N, 2).T == serial[i][t]).all(), (gemm, i, t)
+        eng.close()
 
 
 def test_short_chunk_ragged_last_segment(pkg, po, small):

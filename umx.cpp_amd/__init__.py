@@ -116,6 +116,8 @@ def hip_lib():
 
 
 CREATE_QUANTISED_RESIDENT = 0x1
+CREATE_GEMM_F32 = 0x4
+CREATE_DEQUANTISE_AT_LOAD = 0x8
 
 HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
@@ -161,14 +163,16 @@ class Engine:
     the streaming LSTM state carries over until `stream_reset`."""
 
     def __init__(self, targets, hidden, segment_samples=SEGMENT_SAMPLES, device=0, quantised=True,
-                 quantised_resident=False):
+                 quantised_resident=True, gemm=None):
         """quantised: hand the file's u8/u16 bytes (+ scale/offset) to the engine instead of fp32 arrays;
-        quantised_resident: keep them that way in HBM (BASELINE config 5, umx_hip_create_ex)."""
+        quantised_resident: keep them that way in HBM (the default; BASELINE config 5) or expand them at load;
+        gemm: "bf16x3" (default: three-term bf16 split on the bf16 matrix cores) or "f32" (fp32 MFMA)."""
         self.lib = hip_lib()
         views, self._keep = views_from_file_tensors(targets, quantised)
         h = C.c_void_p()
         rc = self.lib.umx_hip_create_ex(C.byref(h), device, hidden, segment_samples, views, len(views),
-                                        CREATE_QUANTISED_RESIDENT if quantised_resident else 0)
+                                        (0 if quantised_resident else CREATE_DEQUANTISE_AT_LOAD) |
+                                        (CREATE_GEMM_F32 if (gemm or os.environ.get("UMX_GEMM", "bf16x3")) == "f32" else 0))
         if rc != UMX_OK:
             raise UmxError(rc, self.lib.umx_hip_last_error(None).decode())
         self.h = h
@@ -177,9 +181,9 @@ class Engine:
         self.T = self.lib.umx_hip_nb_frames(h)
 
     @classmethod
-    def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0, quantised_resident=False):
+    def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0, quantised_resident=True, gemm=None):
         hidden, targets = ggml.read_model(path)
-        return cls(targets, hidden, segment_samples, device, quantised_resident=quantised_resident)
+        return cls(targets, hidden, segment_samples, device, quantised_resident=quantised_resident, gemm=gemm)
 
     def weight_bytes(self):
         return int(self.lib.umx_hip_weight_bytes(self.h))

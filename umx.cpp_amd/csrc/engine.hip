@@ -18,6 +18,7 @@
 
 #include "common.h"
 #include "gemm_kernels.h"
+#include "gemm_bf16x3.h"
 #include "lstm_kernels.h"
 #include "lstm_wavefront.h"
 #include "track_kernels.h"
@@ -42,6 +43,7 @@ struct QMat
 struct TargetBufs // weights of one target (shared by both pipeline slots)
 {
     QMat fc1_q, ih_q[3], fc2_q, fc3_q; // used instead of the fp32 matrix when .q != nullptr
+    unsigned short *fc1_bx = nullptr, *ih_bx[3] = {}, *fc2_bx = nullptr, *fc3_bx = nullptr; // bf16 planes [3][N][K] (gemm_bf16x3.h)
     float *fc1_w = nullptr, *in_scale = nullptr, *in_mean = nullptr, *bn1[4] = {};
     float *ih_w[3] = {}, *ih_b[3] = {};
     float *fc2_w = nullptr, *bn2[4] = {};
@@ -158,6 +160,7 @@ struct umx_hip_ctx
     int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors,
              unsigned create_flags);
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
+    bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
     unsigned char *whh_q[3] = {}; // u8-resident W_hh (create flag), same layout as whh[]
     float whh_s[3][8] = {}, whh_o[3][8] = {};
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
@@ -283,7 +286,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         return true;
     };
 
-    const bool keepq = create_flags & UMX_CREATE_QUANTISED_RESIDENT;
+    const bool keepq = !(create_flags & UMX_CREATE_DEQUANTISE_AT_LOAD); // u8/u16 views stay as they are (config 5)
     auto view = [&](int tg, const std::string &name) -> const umx_tensor_view * {
         auto it = idx[tg].find(name);
         return it == idx[tg].end() ? nullptr : it->second;
@@ -322,6 +325,22 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     };
     auto is_q = [&](const umx_tensor_view *tv, int dtype, size_t expect) {
         return keepq && tv && tv->dtype == dtype && nelems(tv) == expect;
+    };
+
+    gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // bf16x3 is the default (gemm_bf16x3.h)
+    const bool bx = gemm_bf16x3;
+    // fp32 matrix (kernel layout, padded) -> device; as three bf16 planes when the bf16x3 GEMMs are selected
+    auto upload_matrix = [&](float **dst_f32, unsigned short **dst_bx, const std::vector<float> &w) -> int {
+        if (!bx)
+        {
+            weight_bytes += w.size() * sizeof(float);
+            return upload(dst_f32, w);
+        }
+        std::vector<unsigned short> planes(3 * w.size());
+        for (size_t i = 0; i < w.size(); ++i)
+            split3_host(w[i], planes[i], planes[w.size() + i], planes[2 * w.size() + i]);
+        weight_bytes += planes.size() * sizeof(unsigned short);
+        return upload(dst_bx, planes);
     };
 
     const int G = 4 * Hl; // gate rows per direction
@@ -392,9 +411,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             w.assign((size_t)H * KX, 0.f);
             for (int o = 0; o < H; ++o)
                 memcpy(&w[(size_t)o * KX], &v[(size_t)o * NIN], sizeof(float) * NIN);
-            if (int rc = upload(&b.fc1_w, w))
+            if (int rc = upload_matrix(&b.fc1_w, &b.fc1_bx, w))
                 return rc;
-            weight_bytes += w.size() * sizeof(float);
         }
         const char *bnn[4] = {"running_mean", "running_var", "weight", "bias"};
         for (int k = 0; k < 4; ++k)
@@ -426,9 +444,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         {
             if (!get(tg, "fc2.weight", (size_t)H * 2 * H, v))
                 return UMX_ERR_MODEL;
-            if (int rc = upload(&b.fc2_w, v))
+            if (int rc = upload_matrix(&b.fc2_w, &b.fc2_bx, v))
                 return rc;
-            weight_bytes += v.size() * sizeof(float);
         }
         if (const umx_tensor_view *tv = view(tg, "fc3.weight"); is_q(tv, UMX_DTYPE_U16, (size_t)NOUT * H))
         {
@@ -444,9 +461,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 return UMX_ERR_MODEL;
             w.assign((size_t)NOUT_PAD * H, 0.f);
             memcpy(w.data(), v.data(), sizeof(float) * (size_t)NOUT * H);
-            if (int rc = upload(&b.fc3_w, w))
+            if (int rc = upload_matrix(&b.fc3_w, &b.fc3_bx, w))
                 return rc;
-            weight_bytes += w.size() * sizeof(float);
         }
         // LSTM: permute gate rows so a workgroup's 64 columns (g,u) are contiguous
         for (int l = 0; l < 3; ++l)
@@ -504,9 +520,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             }
             if (!ih_q)
             {
-                if (int rc = upload(&b.ih_w[l], ihw))
+                if (int rc = upload_matrix(&b.ih_w[l], &b.ih_bx[l], ihw))
                     return rc;
-                weight_bytes += ihw.size() * sizeof(float);
             }
             if (int rc = upload(&b.ih_b[l], ihb))
                 return rc;
@@ -684,6 +699,16 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                                 reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3, BQ_U16>)};
         for (const void *fn : gemms)
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+        const void *bxs[8] = {reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_F32>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_U8>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_IH, BQ_F32>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_IH, BQ_U8>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC2, BQ_F32>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC2, BQ_U16>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC3, BQ_F32>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC3, BQ_U16>)};
+        for (const void *fn : bxs)
+            UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
     }
     UMX_HIP_CHECK(hipDeviceSynchronize());
     return UMX_OK;
@@ -860,30 +885,55 @@ void umx_hip_ctx::launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, con
             bq = q.type;
         }
     }
-#if GEMM_SWIZZLE
+    if (gemm_bf16x3 && bq == BQ_F32) // weights resident as three bf16 planes
+        for (int i = 0; i < nact; ++i)
+        {
+            const TargetBufs &b = tb[active[i]];
+            g.t[i].Bq = mode == G_FC1 ? b.fc1_bx : mode == G_IH ? b.ih_bx[layer] : mode == G_FC2 ? b.fc2_bx : b.fc3_bx;
+        }
     const dim3 grid((unsigned)round_up((g.N / GEMM_BN) * (g.M / GEMM_BM), 8), 1, nact), block(256);
-#else
-    const dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, nact), block(256);
-#endif
-    switch (mode)
-    {
-    case G_FC1:
-        if (bq == BQ_U8) hipLaunchKernelGGL((gemm_tn_kernel<G_FC1, BQ_U8>), grid, block, GEMM_LDS_BYTES, st, g);
-        else hipLaunchKernelGGL((gemm_tn_kernel<G_FC1, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
-        break;
-    case G_IH:
-        if (bq == BQ_U8) hipLaunchKernelGGL((gemm_tn_kernel<G_IH, BQ_U8>), grid, block, GEMM_LDS_BYTES, st, g);
-        else hipLaunchKernelGGL((gemm_tn_kernel<G_IH, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
-        break;
-    case G_FC2:
-        if (bq == BQ_U16) hipLaunchKernelGGL((gemm_tn_kernel<G_FC2, BQ_U16>), grid, block, GEMM_LDS_BYTES, st, g);
-        else hipLaunchKernelGGL((gemm_tn_kernel<G_FC2, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
-        break;
-    default:
-        if (bq == BQ_U16) hipLaunchKernelGGL((gemm_tn_kernel<G_FC3, BQ_U16>), grid, block, GEMM_LDS_BYTES, st, g);
-        else hipLaunchKernelGGL((gemm_tn_kernel<G_FC3, BQ_F32>), grid, block, GEMM_LDS_BYTES, st, g);
-        break;
-    }
+#define UMX_LAUNCH(KERNEL, LDS) hipLaunchKernelGGL((KERNEL), grid, block, LDS, st, g)
+    if (gemm_bf16x3)
+        switch (mode)
+        {
+        case G_FC1:
+            if (bq == BQ_U8) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_U8>), BX_LDS_BYTES);
+            else UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_F32>), BX_LDS_BYTES);
+            break;
+        case G_IH:
+            if (bq == BQ_U8) UMX_LAUNCH((gemm_bf16x3_kernel<G_IH, BQ_U8>), BX_LDS_BYTES);
+            else UMX_LAUNCH((gemm_bf16x3_kernel<G_IH, BQ_F32>), BX_LDS_BYTES);
+            break;
+        case G_FC2:
+            if (bq == BQ_U16) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC2, BQ_U16>), BX_LDS_BYTES);
+            else UMX_LAUNCH((gemm_bf16x3_kernel<G_FC2, BQ_F32>), BX_LDS_BYTES);
+            break;
+        default:
+            if (bq == BQ_U16) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC3, BQ_U16>), BX_LDS_BYTES);
+            else UMX_LAUNCH((gemm_bf16x3_kernel<G_FC3, BQ_F32>), BX_LDS_BYTES);
+            break;
+        }
+    else
+        switch (mode)
+        {
+        case G_FC1:
+            if (bq == BQ_U8) UMX_LAUNCH((gemm_tn_kernel<G_FC1, BQ_U8>), GEMM_LDS_BYTES);
+            else UMX_LAUNCH((gemm_tn_kernel<G_FC1, BQ_F32>), GEMM_LDS_BYTES);
+            break;
+        case G_IH:
+            if (bq == BQ_U8) UMX_LAUNCH((gemm_tn_kernel<G_IH, BQ_U8>), GEMM_LDS_BYTES);
+            else UMX_LAUNCH((gemm_tn_kernel<G_IH, BQ_F32>), GEMM_LDS_BYTES);
+            break;
+        case G_FC2:
+            if (bq == BQ_U16) UMX_LAUNCH((gemm_tn_kernel<G_FC2, BQ_U16>), GEMM_LDS_BYTES);
+            else UMX_LAUNCH((gemm_tn_kernel<G_FC2, BQ_F32>), GEMM_LDS_BYTES);
+            break;
+        default:
+            if (bq == BQ_U16) UMX_LAUNCH((gemm_tn_kernel<G_FC3, BQ_U16>), GEMM_LDS_BYTES);
+            else UMX_LAUNCH((gemm_tn_kernel<G_FC3, BQ_F32>), GEMM_LDS_BYTES);
+            break;
+        }
+#undef UMX_LAUNCH
 }
 
 // stft -> |.|, crop/stack -> fc1/bn1/tanh -> input projection of LSTM layer 0
@@ -1440,6 +1490,34 @@ int umx_hip_ctx::phase_end(float *const out_host[4])
     return UMX_OK;
 }
 
+// ---------------------------------------------------------------- debugging: LDS isolation guard
+// A victim workgroup fills 36 KB of LDS with a pattern and keeps verifying it for a while; run beside other
+// kernels it shows whether anything else writes into its LDS allocation.
+__global__ __launch_bounds__(256) void lds_guard_kernel(unsigned *errs, int rounds)
+{
+    __shared__ unsigned g[9216]; // 36 KB
+    const unsigned salt = blockIdx.x * 2654435761u;
+    for (int i = threadIdx.x; i < 9216; i += 256)
+        g[i] = salt ^ (unsigned)i;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r)
+    {
+        unsigned bad = 0;
+        for (int i = threadIdx.x; i < 9216; i += 256)
+            bad += (g[i] != (salt ^ (unsigned)i));
+        if (bad)
+        {
+            atomicAdd(errs, bad);
+            atomicAdd(errs + 1, 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 9216; i += 256)
+            g[i] = salt ^ (unsigned)i;
+        __syncthreads();
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
 // ---------------------------------------------------------------- C-ABI
 extern "C"
 {
@@ -1451,8 +1529,11 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
 {
     unsigned cf = 0;
     if (const char *e = getenv("UMX_WEIGHTS_RESIDENT")) // lets umx-cli switch without an API change
-        if (std::string(e) == "quantised" || std::string(e) == "quantized")
-            cf |= UMX_CREATE_QUANTISED_RESIDENT;
+        if (std::string(e) == "expanded" || std::string(e) == "f32")
+            cf |= UMX_CREATE_DEQUANTISE_AT_LOAD;
+    if (const char *e = getenv("UMX_GEMM"))
+        if (std::string(e) == "f32")
+            cf |= UMX_CREATE_GEMM_F32;
     return umx_hip_create_ex(out, device, hidden_size, segment_samples, tensors, n_tensors, cf);
 }
 
@@ -1610,6 +1691,31 @@ int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int lengt
     if (offset < 0)
         offset = rand() % UMX_MAX_SHIFT; // umx.cpp:115 (never seeded in the reference)
     return ctx->track(audio_host, length, offset, out_host, flags, progress, progress_user);
+}
+
+// debugging: queue `launches` LDS-guard kernels on a private stream (they run beside whatever the caller
+// queues next); read the counters back with launches == 0 (returns words corrupted, events in out2[0..1])
+int umx_hip_debug_lds_guard(umx_hip_ctx *ctx, int launches, int rounds, unsigned *out2)
+{
+    static hipStream_t gs = nullptr;
+    static unsigned *errs = nullptr;
+    if (!ctx)
+        return UMX_ERR_ARG;
+    if (!gs)
+    {
+        if (hipStreamCreateWithFlags(&gs, hipStreamNonBlocking) != hipSuccess || hipMalloc(&errs, 8) != hipSuccess)
+            return UMX_ERR_HIP;
+        (void)hipMemset(errs, 0, 8);
+    }
+    for (int i = 0; i < launches; ++i)
+        hipLaunchKernelGGL(lds_guard_kernel, dim3(512), dim3(256), 0, gs, errs, rounds);
+    if (launches == 0 && out2)
+    {
+        (void)hipStreamSynchronize(gs);
+        (void)hipMemcpy(out2, errs, 8, hipMemcpyDeviceToHost);
+        (void)hipMemset(errs, 0, 8);
+    }
+    return UMX_OK;
 }
 
 int umx_hip_segment_begin(umx_hip_ctx *ctx, const float *audio_host, int n, unsigned flags)

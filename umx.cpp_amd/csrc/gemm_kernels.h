@@ -78,6 +78,64 @@ __device__ __forceinline__ float4 scale_shift(float4 a, float4 sc, float4 mn)
 // Register budget of the two-slot pipeline (engine.hip): two GEMM blocks (136 VGPRs allocated) must fit a CU
 // beside two 8-wave LSTM workgroups of the other slot (104 each): 2 x 104 + 2 x 136 = 480 <= 512 per SIMD lane.
 // An LSTM kernel above 120 VGPRs halves the overlapped GEMMs' occupancy (measured: 0.9 -> 2.2 ms).
+// Epilogue shared by the fp32-MFMA and the bf16x3 kernels: lane owns column n, rows (r&3) + 8*(r>>2) + 4*lh of
+// each 32x32 accumulator tile (the layout of both v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16).
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmArgs &args, int m0, int n0, int wm, int wn,
+                                              int lr, int lh, const floatx16 &acc00, const floatx16 &acc01,
+                                              const floatx16 &acc10, const floatx16 &acc11)
+{
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+    {
+        const int n = n0 + wn * 64 + ni * 32 + lr;
+        float rm = 0.f, sd = 1.f, gw = 1.f, gb = 0.f, osc = 1.f, omn = 0.f;
+        if (MODE == G_IH)
+            gb = tg.e0[n];
+        else
+        {
+            rm = tg.e0[n];
+            sd = sqrtf(tg.e1[n] + 1e-5f); // inference.cpp:94-95
+            gw = tg.e2[n];
+            gb = tg.e3[n];
+        }
+        if (MODE == G_FC3)
+        {
+            osc = tg.q0[n];
+            omn = tg.q1[n];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+            {
+                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float y = mi == 0 ? (ni == 0 ? acc00[r] : acc01[r]) : (ni == 0 ? acc10[r] : acc11[r]);
+                if (MODE == G_IH)
+                {
+                    tg.C[(size_t)m * args.ldc + n] = y + gb; // lstm.cpp:132-135: W_ih x + b_ih
+                }
+                else
+                {
+                    y = ((y - rm) / sd) * gw + gb; // batchnorm, inference.cpp:93-97 order
+                    if (MODE == G_FC1)
+                        tg.C[(size_t)m * args.ldc + n] = tanhf(y);
+                    else if (MODE == G_FC2)
+                        tg.C[(size_t)m * args.ldc + n] = fmaxf(y, 0.f);
+                    else if (n < NOUT && m < args.T)
+                    {
+                        y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
+                        if (tg.dbg)
+                            tg.dbg[(size_t)m * NOUT + n] = y;
+                        const int c = n >= NBINS ? 1 : 0, b = n - c * NBINS;
+                        const size_t idx = ((size_t)c * args.T + m) * NBINS + b;
+                        tg.C[idx] = y * tg.aux[idx]; // inference.cpp:175-183
+                    }
+                }
+            }
+    }
+}
+
 enum GemmBType
 {
     BQ_F32 = 0,
@@ -248,56 +306,7 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_tn_ke
 #undef UMX_FINISH_B
 #undef UMX_MFMA4
 
-    // epilogue: lane owns column n, rows (r&3) + 8*(r>>2) + 4*lh of each 32x32 tile
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-    {
-        const int n = n0 + wn * 64 + ni * 32 + lr;
-        float rm = 0.f, sd = 1.f, gw = 1.f, gb = 0.f, osc = 1.f, omn = 0.f;
-        if (MODE == G_IH)
-            gb = tg.e0[n];
-        else
-        {
-            rm = tg.e0[n];
-            sd = sqrtf(tg.e1[n] + 1e-5f); // inference.cpp:94-95
-            gw = tg.e2[n];
-            gb = tg.e3[n];
-        }
-        if (MODE == G_FC3)
-        {
-            osc = tg.q0[n];
-            omn = tg.q1[n];
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-            {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float y = mi == 0 ? (ni == 0 ? acc00[r] : acc01[r]) : (ni == 0 ? acc10[r] : acc11[r]);
-                if (MODE == G_IH)
-                {
-                    tg.C[(size_t)m * args.ldc + n] = y + gb; // lstm.cpp:132-135: W_ih x + b_ih
-                }
-                else
-                {
-                    y = ((y - rm) / sd) * gw + gb; // batchnorm, inference.cpp:93-97 order
-                    if (MODE == G_FC1)
-                        tg.C[(size_t)m * args.ldc + n] = tanhf(y);
-                    else if (MODE == G_FC2)
-                        tg.C[(size_t)m * args.ldc + n] = fmaxf(y, 0.f);
-                    else if (n < NOUT && m < args.T)
-                    {
-                        y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
-                        if (tg.dbg)
-                            tg.dbg[(size_t)m * NOUT + n] = y;
-                        const int c = n >= NBINS ? 1 : 0, b = n - c * NBINS;
-                        const size_t idx = ((size_t)c * args.T + m) * NBINS + b;
-                        tg.C[idx] = y * tg.aux[idx]; // inference.cpp:175-183
-                    }
-                }
-            }
-    }
+    gemm_epilogue<MODE>(tg, args, m0, n0, wm, wn, lr, lh, acc00, acc01, acc10, acc11);
 }
 
 } // namespace umx

@@ -5,7 +5,7 @@
 // target_{0..3}.wav (0 = bass, 1 = drums, 2 = other, 3 = vocals).  Exit code 1 on any failure,
 // like the reference.  Extra knobs come from the environment only, so the 3 positionals stay:
 //   UMX_DEVICE=<n>   UMX_NO_WIENER=1   UMX_SHIFT_OFFSET=<n>   UMX_LSTM_STEPWISE=1   UMX_CLI_PER_SEGMENT=1
-//   UMX_WEIGHTS_RESIDENT=quantised
+//   UMX_WEIGHTS_RESIDENT=expanded   UMX_GEMM=f32
 #include "../../include/umx_host.h"
 
 #include <chrono>
