@@ -341,6 +341,34 @@ def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_pat
         eng.close()
 
 
+def test_full_size_pipelined_equals_serial(pkg, tmp_path):
+    """UMX-L at the real segment length (T = 2584): four segments queued back to back -- two LSTM grids, GEMM blocks
+    (bf16 MFMA), FFT and Wiener workgroups all sharing CUs for milliseconds -- against the same four one at a time.
+    Bitwise.  This is the guard for cross-kernel interference."""
+    import torch
+    torch.zeros(1).cuda()
+    H, N, NSEG = 1024, pkg.SEGMENT_SAMPLES, 4
+    p = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=37), H, compress=False)
+    eng = pkg.Engine.from_file(p, N)
+    wave = pkg.ggml.synth_audio(N + 3 * 4096, 700)
+    chunks = [np.ascontiguousarray(wave[:, i * 4096:i * 4096 + N]) for i in range(NSEG)]
+    eng.stream_reset()
+    serial = [eng.infer_segment(c) for c in chunks]
+    ins = [torch.from_numpy(np.ascontiguousarray(c.T).ravel()).cuda() for c in chunks]
+    o = [[torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)] for _ in range(NSEG)]
+    eng.stream_reset()
+    torch.cuda.synchronize()
+    for i in range(NSEG):
+        eng.infer_segment_device(ins[i].data_ptr(), N, [x.data_ptr() for x in o[i]])
+    eng.sync()
+    assert eng.lstm_mode() == 2
+    for i in range(NSEG):
+        for t in range(4):
+            assert (o[i][t].cpu().numpy().reshape(N, 2).T == serial[i][t]).all(), (i, t)
+    eng.close()
+
+
 def test_short_chunk_ragged_last_segment(pkg, po, small):
     """n < segment_samples: T stays n_buf/1024+1, the tail is zeros, outputs are (2,n) (a3, a11)."""
     eng, om, N = small
