@@ -180,12 +180,14 @@ def main():
             per_launch_flops = rec
             per_launch_ms = lstm_ms / 3
             ach = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
-            alg_bytes = 4.0 * (4 * T * 4 * H + 8 * (H // 2) * (2 * H) + 8 * 2 * H + 4 * T * H)  # P + W_hh + b_hh + out
+            whh_el = 4.0 if args.expanded_weights else 1.0  # W_hh resident as fp32 or as the file's u8
+            alg_bytes = 4.0 * (4 * T * 4 * H + 8 * 2 * H + 4 * T * H) + whh_el * 8 * (H // 2) * (2 * H)  # P, b_hh, out, W_hh
             traffic = None
             if H == 1024 and T == 2584 and eng.lstm_mode() >= 1:
-                # profiles/r01_v2_pmc_fetch_write_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate
-                # passes), KB per launch; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section)
-                traffic = (2 * 99207.9 + 41456.0) * 1024
+                # profiles/r01_v5_pmc_fetch_write_per_kernel.csv (u8 W_hh) / r01_v4 (fp32 W_hh): rocprofv3 --pmc
+                # FETCH_SIZE / WRITE_SIZE (separate passes), KB per launch; FETCH_SIZE x2 on gfx950
+                # (MI355X_MICROARCH.md HBM section)
+                traffic = (2 * (99512.3 if args.expanded_weights else 86940.7) + 41456.0) * 1024
             roofline = {"kernel": "lstm_persistent_kernel<64>" if eng.lstm_was_persistent() else "lstm_step_kernel",
                         "bound": "mfma", "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(ach / F32_MFMA_PEAK_TF, 5), "traffic": traffic,
