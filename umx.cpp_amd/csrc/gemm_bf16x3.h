@@ -29,20 +29,34 @@ constexpr int BX_OPERAND_BYTES = 3 * BX_PLANE_BYTES;  // 18,432
 constexpr int BX_BUF_BYTES = 2 * BX_OPERAND_BYTES;    // A planes then B planes: 36,864
 constexpr int BX_LDS_BYTES = 2 * BX_BUF_BYTES;        // 73,728
 
-// x -> (x1, x2, x3) for 8 consecutive values
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 &p1, bf16x8 &p2, bf16x8 &p3)
+// (x0, x1) -> one dword holding (bf16(x0), bf16(x1)), round-to-nearest-even: a single v_cvt_pk_bf16_f32
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float float2e __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1)
 {
+    const float2e v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// x -> (x1, x2, x3) for 8 consecutive values, kept as packed dwords all the way: 11 VALU per pair of values
+// (element-wise __bf16 code compiled to twice the conversions plus register shuffles)
+__device__ __forceinline__ void split3(const float (&x)[8], uint4 &p1, uint4 &p2, uint4 &p3)
+{
+    unsigned o1[4], o2[4], o3[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
     {
-        const __bf16 h1 = (__bf16)x[i];
-        const float r1 = x[i] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        p1[i] = h1;
-        p2[i] = h2;
-        p3[i] = (__bf16)r2;
+        const float x0 = x[2 * i], x1 = x[2 * i + 1];
+        const unsigned h = cvt_pk_bf16(x0, x1);
+        const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+        o1[i] = h;
+        o2[i] = m;
+        o3[i] = cvt_pk_bf16(s0, s1);
     }
+    p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+    p3 = make_uint4(o3[0], o3[1], o3[2], o3[3]);
 }
 
 // host-side twin of split3 (weights at load time); round-to-nearest-even like v_cvt_pk_bf16_f32
@@ -147,11 +161,11 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
             a1 = scale_shift(a1, rs1, rm1);                                                            \
         }                                                                                              \
         const float xs[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};                          \
-        bf16x8 p1, p2, p3;                                                                             \
+        uint4 p1, p2, p3;                                                                              \
         split3(xs, p1, p2, p3);                                                                        \
-        *reinterpret_cast<bf16x8 *>(base) = p1;                                                        \
-        *reinterpret_cast<bf16x8 *>(base + BX_PLANE_BYTES) = p2;                                       \
-        *reinterpret_cast<bf16x8 *>(base + 2 * BX_PLANE_BYTES) = p3;                                   \
+        *reinterpret_cast<uint4 *>(base) = p1;                                                         \
+        *reinterpret_cast<uint4 *>(base + BX_PLANE_BYTES) = p2;                                        \
+        *reinterpret_cast<uint4 *>(base + 2 * BX_PLANE_BYTES) = p3;                                    \
         if (BQ == BQ_F32)                                                                              \
         {                                                                                              \
             *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES) = rb1;                                 \
@@ -174,11 +188,11 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
                 ws[0] = lo.x; ws[1] = lo.y; ws[2] = lo.z; ws[3] = lo.w;                                \
                 ws[4] = hi.x; ws[5] = hi.y; ws[6] = hi.z; ws[7] = hi.w;                                \
             }                                                                                          \
-            bf16x8 w1, w2, w3;                                                                         \
+            uint4 w1, w2, w3;                                                                          \
             split3(ws, w1, w2, w3);                                                                    \
-            *reinterpret_cast<bf16x8 *>(base + BX_OPERAND_BYTES) = w1;                                 \
-            *reinterpret_cast<bf16x8 *>(base + BX_OPERAND_BYTES + BX_PLANE_BYTES) = w2;                \
-            *reinterpret_cast<bf16x8 *>(base + BX_OPERAND_BYTES + 2 * BX_PLANE_BYTES) = w3;            \
+            *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES) = w1;                                  \
+            *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES + BX_PLANE_BYTES) = w2;                 \
+            *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES + 2 * BX_PLANE_BYTES) = w3;             \
         }                                                                                              \
     }
 
