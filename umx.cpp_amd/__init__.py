@@ -108,6 +108,7 @@ def hip_lib():
     lib.umx_hip_segment_begin.argtypes = [C.c_void_p, _fp, C.c_int, C.c_uint]
     lib.umx_hip_segment_lstm_layer.argtypes = [C.c_void_p, C.c_int]
     lib.umx_hip_segment_end.argtypes = [C.c_void_p, C.POINTER(_fp)]
+    lib.umx_hip_debug_lds_guard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint)]
     lib.umx_hip_split_inference.argtypes = [C.c_void_p, _fp, C.c_int, C.POINTER(_fp), C.c_uint, C.c_void_p, C.c_void_p]
     lib.umx_hip_shift_inference.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(_fp), C.c_uint, C.c_void_p,
                                             C.c_void_p]
@@ -127,7 +128,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_weight_bytes", "u
                "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
-               "umx_hip_split_inference", "umx_hip_shift_inference"]
+               "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard"]
 
 
 def views_from_file_tensors(targets, quantised=True):
