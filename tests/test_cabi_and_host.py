@@ -107,3 +107,28 @@ def test_backend_error_is_propagated(pkg):
     with pytest.raises(pkg.HostError) as e:
         pkg.split_inference(be, np.zeros((2, 5000), np.float32), 4096)
     assert e.value.code == 13
+
+
+def test_device_code_has_no_low_half_op_sel_on_packed_fp32(tmp_path):
+    """MI355X erratum found in round 1 (tools/pk_mfma_probe.hip): v_pk_add/mul/fma_f32 whose LOW result
+    half selects the HIGH half of a source (op_sel bit set) return wrong values while a co-resident wave issues
+    v_mfma_f32_32x32x16_bf16 -- which this engine's GEMMs do all the time.  The build therefore uses
+    -fno-slp-vectorize and scalar horizontal adds; this test disassembles the device code and fails if a compiler
+    or source change reintroduces such a form."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    mk = (ROOT / "umx.cpp_amd" / "Makefile").read_text()
+    assert "-fno-slp-vectorize" in mk
+    out = tmp_path / "engine.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "umx.cpp_amd" / "csrc" / "engine.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bad = []
+    for line in out.read_text().splitlines():
+        m = re.match(r"\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[([01,]+)\]", line)
+        if m and "1" in m.group(2):
+            bad.append(line.strip())
+    assert not bad, bad[:5]

@@ -41,6 +41,16 @@ namespace umx
 {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+// .x + .y as ONE scalar v_add_f32.  Left to the compiler this becomes v_pk_add_f32 v, v, v op_sel:[0,1]
+// op_sel_hi:[1,0]; packed fp32 ops whose low half selects the HIGH half of src1 return wrong results on MI355X
+// while a co-resident wave issues v_mfma_f32_32x32x16_bf16 (tools/pk_mfma_probe.hip).  The same-register
+// form measured clean, but this kernel shares its CUs with the bf16 GEMMs all the time: do not depend on it.
+__device__ __forceinline__ float hadd2(float2v v)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
+    return r;
+}
 #ifndef LSTM_DOT_PK
 #define LSTM_DOT_PK 1 // 1: rotations (2m, 2m+1) feed one v_pk_fma_f32 (even-n / odd-n partial sums); 0: 64 v_fmac_f32 +
                       // 15 DPP movs; 2: 64 v_fmac_f32_dpp (rotation folded into the FMA's src0, same order as 0)
@@ -222,7 +232,7 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
             hv.y = hs[w * kpw + i + 1];
             acc = __builtin_elementwise_fma(wv, hv, acc);
         }
-        partial = acc.x + acc.y;
+        partial = hadd2(acc);
     }
     part[w][l] = partial;
     __syncthreads();
@@ -351,7 +361,7 @@ template <int N> struct DotDpp
         DotDppPk<7>::run(W, hbits, acc2);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc)
-            acc[cc] = acc2[cc].x + acc2[cc].y;
+            acc[cc] = hadd2(acc2[cc]);
     }
 };
 #else
@@ -617,7 +627,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                     hk.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hval), 2 * i + 1));
                     acc = __builtin_elementwise_fma(W[i], hk, acc);
                 }
-                (*(part + (step & 1)))[w][l] = acc.x + acc.y;
+                (*(part + (step & 1)))[w][l] = hadd2(acc);
             }
         }
         if (prof)
