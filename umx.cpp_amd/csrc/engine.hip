@@ -1365,6 +1365,19 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     const int stride = (int)((1 - 0.25f) * N); // umx.cpp:181, inference.hpp:15
     const float total_reps = std::ceil((float)L2 / (float)stride); // umx.cpp:208
     float done = 0.f;
+    // A sample is final once the segment that starts at or before it and the one before that have been blended
+    // in: region [offset_i, offset_{i+1}) right after segment i.  It is normalised there and then, and the host
+    // downloads it while the GPU is already busy with the following segments.
+    struct Region
+    {
+        int start, count;
+        hipEvent_t ready;
+    };
+    std::vector<Region> regions;
+    auto cleanup = [&]() {
+        for (Region &r : regions)
+            (void)hipEventDestroy(r.ready);
+    };
     int last_slot = -1, iseg = 0;
     for (long long off = 0; off < L2; off += stride, ++iseg)
     {
@@ -1375,34 +1388,62 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
         const int rc = infer_device(trk_in + 2 * (size_t)offset, n, trk_seg[si], flags);
         wavefront = wf;
         if (rc)
+        {
+            cleanup();
             return rc;
+        }
         hipStream_t st = slot[si].stream;
         if (last_slot >= 0) // accumulate in segment order (two segments overlap by a quarter)
-            UMX_HIP_CHECK(hipStreamWaitEvent(st, trk_acc_ev[last_slot], 0));
+            (void)hipStreamWaitEvent(st, trk_acc_ev[last_slot], 0);
         Stems4 seg;
         for (int t = 0; t < 4; ++t)
             seg.p[t] = reinterpret_cast<float2 *>(trk_seg[si][t]);
         hipLaunchKernelGGL(track_accumulate_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, seg, offset, n, N);
-        UMX_HIP_CHECK(hipEventRecord(trk_acc_ev[si], st));
+        (void)hipEventRecord(trk_acc_ev[si], st);
         last_slot = si;
+        Region rg;
+        rg.start = offset;
+        rg.count = (int)std::min<long long>(off + stride, L2) - offset;
+        hipLaunchKernelGGL(track_normalise_kernel, dim3((rg.count + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, rg.start, rg.count);
+        if (hipEventCreateWithFlags(&rg.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(rg.ready, st) != hipSuccess)
+        {
+            cleanup();
+            set_error("track: event creation failed");
+            return UMX_ERR_HIP;
+        }
+        regions.push_back(rg);
         done += 1.0f / total_reps; // umx.cpp:229 (queued, not finished: the device runs behind the host here)
         if (progress)
             progress(done, progress_user);
     }
-    hipStream_t st = slot[last_slot].stream;
-    hipLaunchKernelGGL(track_normalise_kernel, dim3((L2 + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, L2);
-    UMX_HIP_CHECK(hipGetLastError());
-    if (int rc = umx_hip_sync(this))
-        return rc;
     const auto tt2 = std::chrono::steady_clock::now();
-    for (int t = 0; t < 4; ++t) // umx.cpp:136-147: drop the shift
-        UMX_HIP_CHECK(hipMemcpy(out_host[t], trk_out[t] + 2 * (size_t)lead, sizeof(float) * 2 * (size_t)length, hipMemcpyDeviceToHost));
+    hipError_t cerr = hipSuccess;
+    for (const Region &rg : regions) // umx.cpp:136-147: drop the shift
+    {
+        const long long lo = std::max<long long>(rg.start, lead), hi = std::min<long long>((long long)rg.start + rg.count, (long long)lead + length);
+        if (hi <= lo)
+            continue;
+        if (cerr == hipSuccess)
+            cerr = hipEventSynchronize(rg.ready);
+        for (int t = 0; t < 4 && cerr == hipSuccess; ++t)
+            cerr = hipMemcpy(out_host[t] + 2 * (size_t)(lo - lead), trk_out[t] + 2 * (size_t)lo, sizeof(float) * 2 * (size_t)(hi - lo),
+                             hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (cerr != hipSuccess)
+    {
+        set_error(hipGetErrorString(cerr));
+        return UMX_ERR_HIP;
+    }
+    UMX_HIP_CHECK(hipGetLastError());
+    if (int rc = umx_hip_sync(this)) // surfaces a persistent-kernel timeout
+        return rc;
     if (timing)
     {
         const auto tt3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[umx track] %d samples: clear+upload %.1f ms, %d segments %.1f ms, download %.1f ms\n", length,
-                ms(tt0, tt1), iseg, ms(tt1, tt2), ms(tt2, tt3));
+        fprintf(stderr, "[umx track] %d samples: clear+upload %.1f ms, queuing %d segments %.1f ms, segments + overlapped download %.1f ms\n",
+                length, ms(tt0, tt1), iseg, ms(tt1, tt2), ms(tt2, tt3));
     }
     return UMX_OK;
 }

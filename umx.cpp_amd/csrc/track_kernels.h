@@ -36,12 +36,13 @@ __global__ void track_accumulate_kernel(Stems4 track, float *sum_w, Stems4 seg, 
         sum_w[(size_t)offset + k] += w;
 }
 
-// umx.cpp:264-273: out /= sum_weight
-__global__ void track_normalise_kernel(Stems4 track, const float *sum_w, int length)
+// umx.cpp:264-273: out /= sum_weight, for samples [start, start + count)
+__global__ void track_normalise_kernel(Stems4 track, const float *sum_w, int start, int count)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-    if (k >= length)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (i >= count)
         return;
+    const size_t k = (size_t)start + i;
     const float sw = sum_w[k];
     float2 o = track.p[t][k];
     o.x /= sw;
