@@ -110,8 +110,10 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
     const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
     const int K = args.K, lda = args.lda;
 
-    // staging: thread t handles row t >> 1 and the 8 consecutive k of half t & 1, of A and of each B plane
-    const int st_row = tid >> 1, st_half = tid & 1;
+    // staging: lane l of wave w handles row 32 w + (l & 31) and the 8 consecutive k of half l >> 5, of A and of each
+    // B plane -- the same (row, half) -> lane pattern the fragment reads use, so the ds_write_b128 are as
+    // conflict-free as the ds_read_b128 (row stride 48 B: 16 consecutive rows hit 16 distinct 4-bank groups)
+    const int st_row = (tid & 31) + 32 * (tid >> 6), st_half = (tid >> 5) & 1;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tg.A), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(tg.Bq), 0, 0x7fffffff, 0x00020000);
     constexpr int BEL = BQ == BQ_U8 ? 1 : 2; // bytes per resident B element (bf16 plane, u16 or u8)
