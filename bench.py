@@ -205,6 +205,20 @@ def main():
                         "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 5),
                         "traffic": None}
         gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        # the GEMM kernels against their own roof, stand-alone durations: fp32-equivalent (algorithmic) flops, and for
+        # the bf16x3 flavour the six bf16 products it actually issues per fp32 product, against the dense bf16 peak
+        gemm_alone_ms = stage_alone_ms.get("fc1", 0) + stage_alone_ms.get("fc2", 0) + stage_alone_ms.get("fc3_mask", 0) + \
+            sum(stage_alone_ms.get(f"lstm_ih{l}", 0.0) for l in range(3))
+        flavour = args.gemm or os.environ.get("UMX_GEMM", "bf16x3")
+        gemm_view = None
+        if gemm_alone_ms > 0:
+            alg_tf = gemm_flops / (gemm_alone_ms * 1e-3) / 1e12
+            gemm_view = {"kernel": "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel", "bound": "mfma",
+                         "ms_alone": round(gemm_alone_ms, 3), "algorithmic_TFLOPs": round(alg_tf, 1),
+                         "frac_of_f32_mfma_peak": round(alg_tf / F32_MFMA_PEAK_TF, 3)}
+            if flavour == "bf16x3":
+                gemm_view.update({"issued_bf16_TFLOPs": round(6 * alg_tf, 1), "bf16_mfma_peak": 2500.0,
+                                  "frac_of_bf16_mfma_peak": round(6 * alg_tf / 2500.0, 3)})
         stream_ms = sum(stage_ms.get(k, 0.0) for k in ("stft", "wiener", "istft", "ola"))
         stream_gbs = sum(byt.values()) / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else None
         line = {
@@ -231,6 +245,7 @@ def main():
             "stages_ms_unpipelined": {k: round(v, 4) for k, v in stage_alone_ms.items()},
             "ms_per_segment_unpipelined": round(serial_ms, 3),
             "gemm_tflops": round(gemm_tf, 2) if gemm_tf else None,
+            "gemm_view": gemm_view,
             "streaming_gbs": round(stream_gbs, 1) if stream_gbs else None,
             "outputs_finite": finite,
         }
