@@ -1,7 +1,7 @@
 // lstm_kernels.h -- the 3-layer bidirectional streaming LSTM recurrence (lstm.cpp:101-179).
 //
-// The input projection W_ih x_t + b_ih for all frames is a batched MFMA GEMM (gemm_kernels.h,
-// mode G_IH) -- legal because it has no recurrence.  What is left per (target, layer, dir)
+// The input projection W_ih x_t + b_ih for all frames is a batched MFMA GEMM (gemm_bf16x3.h /
+// gemm_kernels.h, mode G_IH) -- legal because it has no recurrence.  What is left per (target, layer, dir)
 // "chain" is strictly serial:  gates_t = (P_t + W_hh h_{t-1}) + b_hh, i|f|g|o split
 // (lstm.cpp:143-152), c = sig(f) c + sig(i) tanh(g), h = sig(o) tanh(c).
 // 4 targets x 2 directions = 8 independent chains per layer run concurrently.
@@ -10,7 +10,7 @@
 // A slice owns the 64 gate columns of its units; lane l of every wave is gate column
 // l = 4*u + g (unit u, gate g: the four gates of a unit sit in one DPP quad); wave w owns the
 // k-range [w*Hl/8, (w+1)*Hl/8) of the W_hh . h contraction.
-//   W    float [chains][S][Hl][64]     (k-major: a wave reads 64 consecutive floats per k)
+//   W    float [chains][S][Hl][64]     (k-major; or the file's u8 in the same layout + per-chain scale/offset)
 //   bhh  float [chains][S][64]
 //   P    float [Tp][2][S][64] per target (GEMM output, columns permuted to match)
 // For Hl = 512: S = 32 slices -> 256 workgroups, W slice = 128 KiB fp32 = 64 VGPRs per lane.
@@ -21,8 +21,12 @@
 //     exchanged between the chain's workgroups through 8-byte {tag = step, value} granules
 //     ("the data is the flag": one naturally aligned 8-byte store per value, polled with
 //     L1-bypassing loads, no fences).  Each wave polls exactly the Hl/8 (<= 64) granules of its
-//     own k-range, one per lane, and broadcasts them lane -> SGPR pair (v_readlane) into
-//     v_pk_fma_f32, so h never goes through LDS.  Two granule slots (step parity) are enough: a
+//     own k-range, one per lane.  Hl = 512: lane (j, r) owns unit j's 4 gate columns and the 16 k of row r;
+//     the polled h is rotated inside each 16-lane row with DPP row_ror and rotation pairs feed
+//     v_pk_fma_f32 (smaller Hl: lane -> SGPR-pair broadcast with v_readlane), so h never goes through
+//     LDS.  The W_ih x + b_ih rows arrive through an LDS ring filled 16 rows at a time with
+//     global_load_lds, 16-32 steps ahead (a per-step HBM load in a polling wave would put the loaded HBM
+//     latency in front of every step: vmcnt retires in order).  Two granule slots (step parity) are enough: a
 //     producer can only overwrite slot p two steps later, which needs every consumer's next h,
 //     i.e. every consumer is past its reads.
 //     Placement: measured on MI355X (tools/handoff_probe.hip) a write-through (sc1) store +
