@@ -3,7 +3,9 @@
 //   stft -> |.| / crop+stack -> 4 x [fc1 bn tanh -> 3-layer BiLSTM -> fc2 bn relu -> fc3 bn scale
 //   relu -> mask*mix] -> Wiener EM -> 4 x istft
 // The four targets run inside the same launches; consecutive segments alternate between two pipeline
-// slots (streams) so that their LSTM layers overlap as an exact wavefront (see struct Slot).
+// slots (streams) so that their LSTM layers overlap as an exact wavefront (see struct Slot).  Also here: the
+// whole-track drivers (split / shift inference with the track resident in HBM), the phased form of a segment
+// for the multi-GPU state-carry mode, weight residency (u8/u16 as stored, or expanded) and the GEMM flavour.
 #include "../../include/umx_hip.h"
 #include <chrono>
 

@@ -1,4 +1,5 @@
-// gemm_kernels.h -- fp32 MFMA GEMM with fused prologue/epilogue for the dense stack
+// gemm_kernels.h -- fp32 MFMA GEMM with fused prologue/epilogue for the dense stack (selected with UMX_GEMM=f32;
+// the default flavour is gemm_bf16x3.h, which shares this file's argument structs, tile order and epilogue)
 // (inference.cpp:75-99 fc1/bn1/tanh, lstm.cpp:132-135 W_ih x + b_ih for ALL frames at once,
 //  inference.cpp:127-140 fc2/bn2/relu, inference.cpp:143-183 fc3/bn3/scale/relu/mask).
 //
