@@ -62,3 +62,18 @@ def test_shard_tracks():
     assert mg.shard_tracks(10, 3, 8) == [3]
     assert mg.shard_tracks(10, 1, 8) == [1, 9]
     assert sorted(sum((mg.shard_tracks(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_python_overlap_add_weights_equal_the_host_driver(pkg):
+    """multigpu._weights (used by the carry / reset mode gather) must be the host driver's umx_transition_weight
+    (umx.cpp:197-206) bit for bit, or the multi-GPU result could not equal the single-GPU one."""
+    import ctypes as C
+    mg = __import__("importlib").import_module("umx_cpp_amd.multigpu")
+    lib = pkg.host_lib()
+    lib.umx_transition_weight.restype = C.c_float
+    lib.umx_transition_weight.argtypes = [C.c_int, C.c_int, C.c_int]
+    for N, n in ((16384, 16384), (16384, 5000), (2646000, 2646000), (2646000, 123457)):
+        w = mg._weights(n, N)
+        ks = [k for k in list(range(0, n, max(1, n // 997))) + [n - 1, N // 2 - 1, N // 2] if 0 <= k < n]
+        for k in ks:
+            assert w[k] == np.float32(lib.umx_transition_weight(k, n, N)), (N, n, k)
