@@ -369,6 +369,42 @@ def test_full_size_pipelined_equals_serial(pkg, tmp_path):
     eng.close()
 
 
+def test_error_behaviour_of_the_c_abi(pkg, model_small, small):
+    """Errors come back as status codes + umx_hip_last_error, never as exit() (the reference prints and exits,
+    model.cpp:59-64, dsp.cpp:27-44); a failed call leaves the context usable."""
+    import ctypes as C
+    eng, om, N = small
+    lib = eng.lib
+    fp = C.POINTER(C.c_float)
+    outs = [np.empty(2 * N, np.float32) for _ in range(4)]
+    arr = (fp * 4)(*[o.ctypes.data_as(fp) for o in outs])
+    a = np.zeros(2 * (N + 1), np.float32)
+    for n in (0, -3, N + 1):  # chunk longer than the stft buffer / empty
+        assert lib.umx_hip_infer_segment(eng.h, a.ctypes.data_as(fp), n, arr, 0) == pkg.ERR_ARG
+        assert b"segment" in lib.umx_hip_last_error(eng.h).lower()
+    assert lib.umx_hip_infer_segment(eng.h, None, 16, arr, 0) == pkg.ERR_ARG
+    assert lib.umx_hip_stream_set(eng.h, None) == pkg.ERR_ARG
+    assert lib.umx_hip_stream_get_layer(eng.h, 3, a.ctypes.data_as(fp)) == pkg.ERR_ARG
+    assert lib.umx_hip_segment_lstm_layer(eng.h, 0) == pkg.ERR_ARG  # no phased segment open
+    assert lib.umx_hip_split_inference(eng.h, a.ctypes.data_as(fp), 0, arr, 0, None, None) == pkg.ERR_ARG
+    # creation: wrong hidden size, missing tensor, bad device
+    path, _, targets = model_small
+    with pytest.raises(pkg.UmxError) as e:
+        pkg.Engine(targets, 100, N)
+    assert e.value.code == pkg.ERR_ARG
+    with pytest.raises(pkg.UmxError) as e:
+        pkg.Engine(targets, 128, N, device=99)
+    assert e.value.code == pkg.ERR_ARG
+    broken = [dict(t) for t in targets]
+    del broken[2]["fc2.weight"]
+    with pytest.raises((pkg.UmxError, KeyError)):
+        pkg.Engine(broken, 128, N)
+    # still alive
+    w = pkg.ggml.synth_audio(N, 800)
+    eng.stream_reset()
+    assert all(np.isfinite(s).all() for s in eng.infer_segment(w))
+
+
 def test_short_chunk_ragged_last_segment(pkg, po, small):
     """n < segment_samples: T stays n_buf/1024+1, the tail is zeros, outputs are (2,n) (a3, a11)."""
     eng, om, N = small
