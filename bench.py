@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
     ap.add_argument("--serial", action="store_true", help="sync after every segment (no cross-segment pipelining)")
+    ap.add_argument("--tracks", type=int, default=1,
+                    help="independent tracks per GPU run together (track lanes, 1..16): one step = one 60 s segment of EVERY "
+                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4)")
+    ap.add_argument("--batched-lstm", action="store_true", help="use the batched LSTM kernel also with --tracks 1")
     ap.add_argument("--track-seconds", type=float, default=0.0,
                     help="also time a whole track of this length through umx_hip_shift_inference (host buffers in and "
                          "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
@@ -117,22 +121,29 @@ def main():
     tmpdir = tempfile.mkdtemp(prefix=f"umx_bench_r{rank}_")
     wpath = os.path.join(tmpdir, "ggml-model-synth-u8.bin")
     pkg.ggml.write_model(wpath, pkg.ggml.synth_weights(H, seed=0), H, compress=False)
+    B = args.tracks
     eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=not args.expanded_weights,
-                               gemm=args.gemm)
+                               gemm=args.gemm, tracks=B, lstm_batched=args.batched_lstm)
     T = eng.T
 
-    wave = pkg.ggml.synth_audio(N, seed=rank)  # each rank: its own track
-    audio = torch.from_numpy(np.ascontiguousarray(wave.T).ravel()).to(dev)  # (2,n) interleaved, in HBM
+    # each rank (and each track lane): its own track
+    audios = [torch.from_numpy(np.ascontiguousarray(pkg.ggml.synth_audio(N, seed=rank * 16 + b).T).ravel()).to(dev)
+              for b in range(B)]  # (2,n) interleaved, in HBM
+    audio = audios[0]
     # two output sets: consecutive segments are in flight together (two pipeline slots) and must not share stems
-    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)] for _ in range(2)]
-    outs = out_sets[0]
+    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4 * B)] for _ in range(2)]
     flags = (pkg.FLAG_NO_WIENER if args.no_wiener else 0) | (pkg.FLAG_LSTM_STEPWISE if args.stepwise_lstm else 0) | \
         (pkg.FLAG_LSTM_FORCE_SAFE if args.safe_lstm else 0) | (pkg.FLAG_LSTM_PROFILE if args.lstm_profile else 0)
     ptr_sets = [[o.data_ptr() for o in st_] for st_ in out_sets]
     nstep = [0]
 
+    aptrs = [a.data_ptr() for a in audios]
+
     def step():
-        eng.infer_segment_device(audio.data_ptr(), N, ptr_sets[nstep[0] & 1], flags)
+        if B == 1:
+            eng.infer_segment_device(audio.data_ptr(), N, ptr_sets[nstep[0] & 1], flags)
+        else:
+            eng.infer_batch_ptrs(aptrs, [N] * B, ptr_sets[nstep[0] & 1], flags)
         nstep[0] += 1
         if args.serial:
             eng.sync()
@@ -165,8 +176,11 @@ def main():
 
     if rank == 0:
         seg_sec = N / 44100.0
-        value = world * args.steps * seg_sec / dt
+        value = world * B * args.steps * seg_sec / dt
         gemm, rec, byt = algorithmic_work(T, H, not args.no_wiener)
+        gemm = {k: v * B for k, v in gemm.items()}  # a stage's time spans every track lane
+        rec *= B
+        byt = {k: v * B for k, v in byt.items()}
         lstm_ms = sum(stage_ms.get(f"lstm_rec{l}", 0.0) for l in range(3))
         gemm_ms = stage_ms.get("fc1", 0) + stage_ms.get("fc2", 0) + stage_ms.get("fc3_mask", 0) + \
             sum(stage_ms.get(f"lstm_ih{l}", 0.0) for l in range(3))
@@ -239,7 +253,8 @@ def main():
                        "weights_resident": ("expanded at load (f32 / bf16 planes)" if args.expanded_weights
                                             else "u8/u16 as in the file (dequantised in the kernels)"),
                        "weight_bytes": eng.weight_bytes(),
-                       "sharding": f"{world} independent segments (one per rank)"},
+                       "tracks_per_gpu": B, "lstm_kernel": "batched (matrix cores)" if eng.lstm_is_batched() else "single-track (VALU)",
+                       "sharding": f"{world} x {B} independent tracks (one 60 s segment of each per step)"},
             "roofline": roofline,
             "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "stages_ms_unpipelined": {k: round(v, 4) for k, v in stage_alone_ms.items()},
@@ -281,7 +296,8 @@ def main():
                     c = pr[layer, w]
                     n = max(int(c[4]), 1)
                     print(f"# lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
-                          f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])})", file=sys.stderr)
+                          f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])})"
+                          f" [poll: sleep {c[6] / n:.0f} first-loads {c[7] / n:.0f}]", file=sys.stderr)
     eng.close()
     if world > 1:
         dist.barrier()

@@ -87,6 +87,22 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
 #define UMX_CREATE_GEMM_F32 0x4u
 int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
+/* Track batching.  The reference is one track per process (umx.cpp:26-97) and its LSTM is one
+ * matrix-vector product per step (lstm.cpp:132-161) -- on a GPU that step is bound by the cross-CU hand-off latency,
+ * not by arithmetic.  A context created for n_tracks (1..16) independent tracks holds that many "track lanes", each
+ * with its own streaming LSTM state (= its own std::array<lstm_data,4>, umx.cpp:167-171) and activation buffers;
+ * umx_hip_infer_batch* runs one segment of every lane per call, and the recurrence of all lanes is ONE launch per
+ * layer in which W_hh.h is a matrix-matrix product on the bf16 matrix cores (three-term split, fp32 accumulate:
+ * csrc/lstm_batch.h).  The LSTM flavour is fixed per context: n_tracks > 1 (or UMX_CREATE_LSTM_BATCHED, environment
+ * UMX_LSTM=batched, on a 1-track context) selects the batched kernel for every call, so a track's result never
+ * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
+ * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise. */
+#define UMX_CREATE_LSTM_BATCHED 0x10u
+#define UMX_MAX_TRACKS 16
+int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                          const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
+int umx_hip_n_tracks(const umx_hip_ctx *ctx);
+int umx_hip_lstm_is_batched(const umx_hip_ctx *ctx);
 size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx); /* HBM bytes held by the model's weight matrices */
 void umx_hip_destroy(umx_hip_ctx *ctx);
 const char *umx_hip_last_error(const umx_hip_ctx *ctx); /* never NULL; also valid for ctx == NULL (create errors) */
@@ -98,18 +114,45 @@ size_t umx_hip_stream_floats(const umx_hip_ctx *ctx);
 int umx_hip_stream_reset(umx_hip_ctx *ctx);                 /* create_lstm_data / umx_lstm_set_zero */
 int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst);  /* checkpoint / multi-GPU hand-off */
 int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src);
+/* The same per track lane (the three above address lane 0); reset with track < 0 clears every lane. */
+int umx_hip_track_stream_reset(umx_hip_ctx *ctx, int track);
+int umx_hip_track_stream_get(umx_hip_ctx *ctx, int track, float *host_dst);
+int umx_hip_track_stream_set(umx_hip_ctx *ctx, int track, const float *host_src);
 
 /* umx_inference (inference.cpp:12-207): one segment -> 4 stems.
  * audio: n interleaved stereo frames (2,n), 1 <= n <= segment_samples.  out[t]: (2,n) each.
- * Host-pointer form: H2D + kernels + D2H, synchronous. */
+ * Host-pointer form: H2D + kernels + D2H, synchronous (umx_inference returns its outputs). */
 int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4],
                           unsigned flags);
-/* Device-pointer form: buffers already in HBM (audio 2*n floats, out[t] 2*n floats each);
- * asynchronous on the context's stream -- call umx_hip_sync before reading results. */
+/* The same without the final wait: H2D, kernels and D2H are queued on the stream of the pipeline slot the segment
+ * runs in (consecutive calls alternate between two slots).  With PINNED host buffers, and distinct buffers for two
+ * consecutive calls, one segment's transfers overlap the other's kernels.  Results are valid after umx_hip_sync. */
+int umx_hip_infer_segment_async(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4],
+                                unsigned flags);
+/* Device-pointer form: buffers already in HBM (audio 2*n floats, out[t] 2*n floats each); asynchronous.
+ * ORDERING CONTRACT: consecutive calls are queued on two alternating internal streams (the cross-segment
+ * pipeline), so (1) audio_dev and out_dev must stay untouched by the caller until umx_hip_sync -- or until the
+ * caller's stream has been ordered behind the engine with umx_hip_order_before; (2) two CONSECUTIVE calls must be
+ * given DISTINCT out_dev buffers (both segments are in flight together); (3) work the caller queued on a stream
+ * of its own that produces audio_dev is ordered in front of the next call with umx_hip_order_after. */
 int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
                                  unsigned flags);
-int umx_hip_sync(umx_hip_ctx *ctx); /* also surfaces a persistent-kernel timeout as UMX_ERR_TIMEOUT */
-void *umx_hip_stream_handle(umx_hip_ctx *ctx); /* the hipStream_t all work is queued on */
+/* One segment of each of n_tracks track lanes (lane i = the i-th track of the context, its LSTM state carries from
+ * call to call): audio[i] = (2,n[i]) interleaved or NULL for a lane that sits this call out (its state is kept),
+ * out[4*i + t] = stem t of track i.  Same three forms and the same ordering contract as above. */
+int umx_hip_infer_batch(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *n,
+                        float *const *out_host, unsigned flags);
+int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *n,
+                              float *const *out_host, unsigned flags);
+int umx_hip_infer_batch_device(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_dev, const int *n,
+                               float *const *out_dev, unsigned flags);
+int umx_hip_sync(umx_hip_ctx *ctx); /* waits for everything queued; also surfaces a persistent-kernel timeout as
+                                       UMX_ERR_TIMEOUT (the streaming state of every lane is then reset to zero) */
+/* hip_stream = a hipStream_t of the caller.  order_after: everything queued by LATER calls on this context starts
+ * only after what is on hip_stream now.  order_before: hip_stream waits for everything queued on the context so far. */
+int umx_hip_order_after(umx_hip_ctx *ctx, void *hip_stream);
+int umx_hip_order_before(umx_hip_ctx *ctx, void *hip_stream);
+void *umx_hip_stream_handle(umx_hip_ctx *ctx); /* the internal hipStream_t the most recent segment was queued on */
 
 /* The whole track on the device: shift_inference (umx.cpp:99-150) around split_inference (umx.cpp:152-295).
  * One upload of the (2,length) interleaved track, the 60 s segments (stride 0.75 * segment_samples,
@@ -144,8 +187,9 @@ int umx_hip_hidden(const umx_hip_ctx *ctx);
 
 /* Stage taps for parity tests (D2H copy of an intermediate of the LAST inferred segment).
  * what: "spec" [2][T][2049] complex | "mix_mag" [2][T][2049] | "x" [T][2976] |
- *       "fc1" [T][H] | "lstm" [T][H] | "mask" [T][4098] (needs UMX_FLAG_DEBUG_TAPS) |
- *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex | "max_abs" [1]
+ *       "fc1" [T][H] | "lstm" [T][H] | "fc2" [T][H] | "mask" [T][4098] (needs UMX_FLAG_DEBUG_TAPS) |
+ *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex | "max_abs" [1];
+ *       suffix "#k" selects track lane k (default 0), "@s" pipeline slot s (default: the most recent)
  * Returns the number of floats written (or needed when dst == NULL), < 0 on error. */
 long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst, size_t capacity_floats);
 

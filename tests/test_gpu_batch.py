@@ -1,0 +1,131 @@
+"""Track batching: B independent tracks through one context, their LSTM recurrence in ONE launch per
+layer on the matrix cores (csrc/lstm_batch.h).  The reference is one track per process (umx.cpp:26-97); what must
+hold is that every track of a batch gets what `umx_inference` (inference.cpp:12-207) would have given it alone:
+  * against the oracle, per track, with the tolerances of test_gpu_parity.py;
+  * bitwise independence from the batch: same bits whatever the lane, the companions and the batch size
+    (B = 1, 4, 16 -- the B = 1 engine is created with the batched kernel), and for the per-step driver;
+  * a lane that sits a call out keeps its streaming state.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_STAGE, TOL_WAVE = 2e-5, 1e-4
+
+
+def _oracle_track(po, om, hidden, waves, n_buf):
+    """One track = consecutive segments with carried state through the oracle; -> ([outs per segment], state)."""
+    st = po.stream_state(hidden)
+    outs = []
+    for w in waves:
+        ref, _ = po.umx_inference(om, w, n_buf=n_buf, state=st)
+        outs.append(ref)
+    return outs, np.array(st, copy=True)
+
+
+@pytest.mark.parametrize("hidden,frames,quantised", [(128, 16, True), (128, 16, False), (512, 24, True), (1024, 40, True)])
+def test_batch_of_tracks_matches_oracle_per_track(pkg, po, tmp_path, hidden, frames, quantised):
+    B, N, NSEG = 4, frames * 1024, 2
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(hidden, seed=41), hidden, compress=False)
+    om = po.Model.load(path)
+    eng = pkg.Engine.from_file(path, N, tracks=B, quantised=quantised)
+    assert eng.lstm_is_batched()
+    # different audio, and ragged lengths, per lane
+    lens = [N, N - 777, N, 5000]
+    waves = [[pkg.ggml.synth_audio(lens[b], 500 + 10 * b + s) for s in range(NSEG)] for b in range(B)]
+    got = [eng.infer_batch([waves[b][s] for b in range(B)]) for s in range(NSEG)]
+    assert eng.lstm_was_persistent()
+    for b in range(B):
+        ref, ref_state = _oracle_track(po, om, hidden, waves[b], N)
+        for s in range(NSEG):
+            for t in range(4):
+                err = float(np.abs(got[s][b][t] - ref[s][t]).max())
+                assert err < TOL_WAVE, (hidden, b, s, t, err)
+        assert rel_l2(eng.track_stream_get(b), ref_state) < TOL_STAGE, (hidden, b)
+    eng.close()
+
+
+def test_track_bits_do_not_depend_on_lane_companions_or_batch_size(pkg, tmp_path):
+    """UMX-L width.  The same track run (a) alone on a 1-track context with the batched kernel, (b) as lane 2 of a
+    4-track batch, (c) as lane 13 of a 16-track batch among other audio, (d) with the per-step driver: identical
+    stems and identical carried state, bit for bit."""
+    H, N, NSEG = 1024, 24 * 1024, 2
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=43), H, compress=False)
+    track = [pkg.ggml.synth_audio(N, 900 + s) for s in range(NSEG)]
+    other = [pkg.ggml.synth_audio(N, 950 + i) for i in range(16)]
+    results = []
+    for B, lane, flags in ((1, 0, 0), (4, 2, 0), (16, 13, 0), (4, 1, pkg.FLAG_LSTM_STEPWISE), (4, 3, pkg.FLAG_LSTM_FORCE_SAFE)):
+        eng = pkg.Engine.from_file(path, N, tracks=B, lstm_batched=True)
+        outs = []
+        for s in range(NSEG):
+            batch = [other[(i + s) % 16] for i in range(B)]
+            batch[lane] = track[s]
+            outs.append(eng.infer_batch(batch, flags)[lane])
+        results.append((outs, eng.track_stream_get(lane), B, lane, flags))
+        eng.close()
+    ref_outs, ref_state = results[0][0], results[0][1]
+    for outs, state, B, lane, flags in results[1:]:
+        assert (state == ref_state).all(), (B, lane, flags)
+        for s in range(NSEG):
+            for t in range(4):
+                assert (outs[s][t] == ref_outs[s][t]).all(), (B, lane, flags, s, t)
+
+
+def test_batched_kernel_agrees_with_single_track_kernel(pkg, tmp_path):
+    """Same track through the single-track (VALU) kernel and the batched (matrix-core) kernel: different summation
+    order, so not bitwise -- but far inside the parity tolerance."""
+    H, N = 1024, 32 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=47), H, compress=False)
+    waves = [pkg.ggml.synth_audio(N, 700 + s) for s in range(2)]
+    e1 = pkg.Engine.from_file(path, N)
+    a = [e1.infer_segment(w, pkg.FLAG_DEBUG_TAPS) for w in waves]
+    la = e1.tap("lstm", 3)
+    sa = e1.stream_get()
+    e1.close()
+    e2 = pkg.Engine.from_file(path, N, tracks=2)
+    b = [e2.infer_batch([w, w], pkg.FLAG_DEBUG_TAPS) for w in waves]
+    lb = e2.tap("lstm#1", 3)
+    sb = e2.track_stream_get(1)
+    e2.close()
+    assert not e1.lstm_is_batched() if e1.h else True
+    assert rel_l2(lb, la) < 1e-5
+    assert rel_l2(sb, sa) < 1e-5
+    for s in range(2):
+        for t in range(4):
+            assert (b[s][0][t] == b[s][1][t]).all()  # two lanes fed the same audio: same bits
+            assert np.abs(b[s][1][t] - a[s][t]).max() < 1e-5
+
+
+def test_idle_lane_keeps_its_state_and_lanes_reset_independently(pkg, model_small):
+    path, om, targets = model_small
+    N = 16 * 1024
+    eng = pkg.Engine(targets, 128, N, tracks=3)
+    w = [pkg.ggml.synth_audio(N, 600 + i) for i in range(3)]
+    eng.infer_batch(w)
+    st = [eng.track_stream_get(i) for i in range(3)]
+    assert all(np.abs(s).max() > 0 for s in st)
+    out = eng.infer_batch([w[1], None, w[0]])  # lane 1 sits out
+    assert out[1] is None
+    assert (eng.track_stream_get(1) == st[1]).all()
+    assert not (eng.track_stream_get(0) == st[0]).all()
+    eng.track_stream_reset(2)
+    assert np.abs(eng.track_stream_get(2)).max() == 0
+    assert (eng.track_stream_get(1) == st[1]).all()
+    # set/get round trip, and a lane restarted from a saved state reproduces its continuation
+    a = eng.infer_batch([None, w[2], None])[1]
+    eng.track_stream_set(1, st[1])
+    b = eng.infer_batch([None, w[2], None])[1]
+    assert all((a[t] == b[t]).all() for t in range(4))
+    # argument errors
+    with pytest.raises(RuntimeError):
+        eng.infer_batch([w[0]] * 4)  # more lanes than the context has
+    with pytest.raises(RuntimeError):
+        eng.infer_batch([None, None, None])
+    eng.close()
+    with pytest.raises(RuntimeError):
+        pkg.Engine(targets, 128, N, tracks=17)

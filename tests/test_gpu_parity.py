@@ -118,49 +118,36 @@ def test_umxl_persistent_modes_and_stepwise_are_bitwise_identical(pkg, tmp_path)
 
 
 def test_pipelined_segments_equal_one_at_a_time(pkg, tmp_path):
-    """Queuing segments back to back (device-pointer API, no sync in between) runs them as a wavefront --
-    fused LSTM launches over 3 consecutive segments at hidden 1024, two pipeline slots otherwise -- and
-    must give the same bits as running them one at a time, including the carried LSTM state (F3)."""
-    import os
+    """Queuing segments back to back (device-pointer API, no sync in between) runs them through the two pipeline
+    slots as an exact wavefront and must give the same bits as running them one at a time, including the carried
+    LSTM state (F3)."""
     import torch
     torch.zeros(1).cuda()  # let torch initialise HIP before the engine's own streams exist
     H, N, NSEG = 1024, 40 * 1024, 6
     path = str(tmp_path / "m.bin")
     pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=29), H, compress=False)
     waves = [pkg.ggml.synth_audio(N, 200 + i) for i in range(NSEG)]
-    results = {}
-    for mode in ("wavefront", "slots"):
-        os.environ["UMX_PIPELINE"] = mode
-        try:  # (the fused-launch experiment only knows expanded fp32 W_hh)
-            eng = pkg.Engine.from_file(path, N, quantised_resident=(mode != "wavefront"))
-        finally:
-            os.environ.pop("UMX_PIPELINE", None)
-        # (a) one at a time (host API syncs after every segment)
-        eng.stream_reset()
-        serial = [eng.infer_segment(w) for w in waves]
-        s_state = eng.stream_get()
-        # (b) back to back through the device-pointer API
-        eng.stream_reset()
-        ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda() for w in waves]
-        outs = [[torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)] for _ in range(NSEG)]
-        torch.cuda.synchronize()
-        for i in range(NSEG):
-            eng.infer_segment_device(ins[i].data_ptr(), N, [o.data_ptr() for o in outs[i]])
-        eng.sync()
-        p_state = eng.stream_get()
-        assert eng.lstm_mode() == 2
-        for i in range(NSEG):
-            for t in range(4):
-                got = outs[i][t].cpu().numpy().reshape(N, 2).T
-                assert (got == serial[i][t]).all(), (mode, i, t)
-        assert (s_state == p_state).all()
-        results[mode] = (serial, s_state)
-        eng.close()
-    # the fused wavefront kernel and the per-layer persistent kernel do the same arithmetic
+    eng = pkg.Engine.from_file(path, N)
+    # (a) one at a time (host API syncs after every segment)
+    eng.stream_reset()
+    serial = [eng.infer_segment(w) for w in waves]
+    s_state = eng.stream_get()
+    # (b) back to back through the device-pointer API
+    eng.stream_reset()
+    ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda() for w in waves]
+    outs = [[torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)] for _ in range(NSEG)]
+    torch.cuda.synchronize()
+    for i in range(NSEG):
+        eng.infer_segment_device(ins[i].data_ptr(), N, [o.data_ptr() for o in outs[i]])
+    eng.sync()
+    p_state = eng.stream_get()
+    assert eng.lstm_mode() == 2
     for i in range(NSEG):
         for t in range(4):
-            assert (results["wavefront"][0][i][t] == results["slots"][0][i][t]).all()
-    assert (results["wavefront"][1] == results["slots"][1]).all()
+            got = outs[i][t].cpu().numpy().reshape(N, 2).T
+            assert (got == serial[i][t]).all(), (i, t)
+    assert (s_state == p_state).all()
+    eng.close()
 
 
 def test_phased_segment_equals_whole_segment(pkg, small):

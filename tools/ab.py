@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""A/B runner for kernel variants on the GPU box: tools/ab.py <outdir> <tracks,tracks,..> <variant .so or 'default'> ...
+Prints one compact line per (variant, tracks): ms/step, x realtime, stand-alone stage times, LSTM phase cycles."""
+import json
+import os
+import subprocess
+import sys
+
+out, tracks, variants = sys.argv[1], [int(x) for x in sys.argv[2].split(",")], sys.argv[3:]
+extra = os.environ.get("AB_BENCH_ARGS", "").split()
+os.makedirs(out, exist_ok=True)
+for v in variants:
+    for b in tracks:
+        env = dict(os.environ)
+        if v != "default":
+            env["UMX_HIP_LIB"] = os.path.abspath(v)
+        tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "")
+        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--lstm-profile"] + extra
+        if b == 1:
+            cmd.append("--batched-lstm")
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        open(f"{out}/{tag}_B{b}.json", "w").write(p.stdout)
+        open(f"{out}/{tag}_B{b}.err", "w").write(p.stderr)
+        try:
+            j = json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception:
+            print(tag, b, "FAILED", p.stderr[-400:])
+            continue
+        al = j["stages_ms_unpipelined"]
+        lstm = sum(al[f"lstm_rec{l}"] for l in range(3)) / 3
+        gemm = al["fc1"] + al["fc2"] + al["fc3_mask"] + sum(al[f"lstm_ih{l}"] for l in range(3))
+        prof = [ln for ln in p.stderr.splitlines() if ln.startswith("# lstm layer 1 wave")]
+        print(f"{tag:12s} B={b:2d} {j['ms_per_step']:8.3f} ms/step {j['value']:9.1f}x  alone: lstm/launch {lstm:7.3f} ms "
+              f"({lstm * 1e3 / j['config']['frames']:.3f} us/step) gemm {gemm:7.3f} serial {j['ms_per_segment_unpipelined']:8.3f}", flush=True)
+        for ln in prof:
+            print("      ", ln[2:], flush=True)

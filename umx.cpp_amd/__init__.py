@@ -76,6 +76,19 @@ def hip_lib():
     lib.umx_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(TensorView), C.c_int]
     lib.umx_hip_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(TensorView), C.c_int,
                                       C.c_uint]
+    lib.umx_hip_create_tracks.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(TensorView), C.c_int,
+                                          C.c_uint, C.c_int]
+    lib.umx_hip_n_tracks.argtypes = [C.c_void_p]
+    lib.umx_hip_lstm_is_batched.argtypes = [C.c_void_p]
+    lib.umx_hip_track_stream_reset.argtypes = [C.c_void_p, C.c_int]
+    lib.umx_hip_track_stream_get.argtypes = [C.c_void_p, C.c_int, _fp]
+    lib.umx_hip_track_stream_set.argtypes = [C.c_void_p, C.c_int, _fp]
+    lib.umx_hip_infer_segment_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_uint]
+    lib.umx_hip_infer_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_uint]
+    lib.umx_hip_infer_batch_async.argtypes = lib.umx_hip_infer_batch.argtypes
+    lib.umx_hip_infer_batch_device.argtypes = lib.umx_hip_infer_batch.argtypes
+    lib.umx_hip_order_after.argtypes = [C.c_void_p, C.c_void_p]
+    lib.umx_hip_order_before.argtypes = [C.c_void_p, C.c_void_p]
     lib.umx_hip_weight_bytes.restype = C.c_size_t
     lib.umx_hip_weight_bytes.argtypes = [C.c_void_p]
     lib.umx_hip_destroy.argtypes = [C.c_void_p]
@@ -119,8 +132,13 @@ def hip_lib():
 CREATE_QUANTISED_RESIDENT = 0x1
 CREATE_GEMM_F32 = 0x4
 CREATE_DEQUANTISE_AT_LOAD = 0x8
+CREATE_LSTM_BATCHED = 0x10
+MAX_TRACKS = 16
 
-HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
+HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "umx_hip_n_tracks", "umx_hip_lstm_is_batched",
+               "umx_hip_track_stream_reset", "umx_hip_track_stream_get", "umx_hip_track_stream_set",
+               "umx_hip_infer_segment_async", "umx_hip_infer_batch", "umx_hip_infer_batch_async",
+               "umx_hip_infer_batch_device", "umx_hip_order_after", "umx_hip_order_before", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
@@ -164,27 +182,36 @@ class Engine:
     the streaming LSTM state carries over until `stream_reset`."""
 
     def __init__(self, targets, hidden, segment_samples=SEGMENT_SAMPLES, device=0, quantised=True,
-                 quantised_resident=True, gemm=None):
+                 quantised_resident=True, gemm=None, tracks=1, lstm_batched=False):
         """quantised: hand the file's u8/u16 bytes (+ scale/offset) to the engine instead of fp32 arrays;
         quantised_resident: keep them that way in HBM (the default; BASELINE config 5) or expand them at load;
-        gemm: "bf16x3" (default: three-term bf16 split on the bf16 matrix cores) or "f32" (fp32 MFMA)."""
+        gemm: "bf16x3" (default: three-term bf16 split on the bf16 matrix cores) or "f32" (fp32 MFMA);
+        tracks: independent track lanes (1..16) run together per call (infer_batch*);
+        lstm_batched: use the batched (matrix-core) LSTM kernel also on a 1-track context."""
         self.lib = hip_lib()
         views, self._keep = views_from_file_tensors(targets, quantised)
         h = C.c_void_p()
-        rc = self.lib.umx_hip_create_ex(C.byref(h), device, hidden, segment_samples, views, len(views),
-                                        (0 if quantised_resident else CREATE_DEQUANTISE_AT_LOAD) |
-                                        (CREATE_GEMM_F32 if (gemm or os.environ.get("UMX_GEMM", "bf16x3")) == "f32" else 0))
+        rc = self.lib.umx_hip_create_tracks(C.byref(h), device, hidden, segment_samples, views, len(views),
+                                            (0 if quantised_resident else CREATE_DEQUANTISE_AT_LOAD) |
+                                            (CREATE_GEMM_F32 if (gemm or os.environ.get("UMX_GEMM", "bf16x3")) == "f32" else 0) |
+                                            (CREATE_LSTM_BATCHED if lstm_batched else 0), tracks)
         if rc != UMX_OK:
             raise UmxError(rc, self.lib.umx_hip_last_error(None).decode())
         self.h = h
         self.hidden = hidden
         self.N = segment_samples
         self.T = self.lib.umx_hip_nb_frames(h)
+        self.tracks = tracks
 
     @classmethod
-    def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0, quantised_resident=True, gemm=None):
+    def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0, quantised_resident=True, gemm=None, tracks=1,
+                  lstm_batched=False, quantised=True):
         hidden, targets = ggml.read_model(path)
-        return cls(targets, hidden, segment_samples, device, quantised_resident=quantised_resident, gemm=gemm)
+        return cls(targets, hidden, segment_samples, device, quantised=quantised, quantised_resident=quantised_resident,
+                   gemm=gemm, tracks=tracks, lstm_batched=lstm_batched)
+
+    def lstm_is_batched(self):
+        return bool(self.lib.umx_hip_lstm_is_batched(self.h))
 
     def weight_bytes(self):
         return int(self.lib.umx_hip_weight_bytes(self.h))
@@ -217,6 +244,19 @@ class Engine:
         a = np.ascontiguousarray(a, np.float32)
         assert a.size == self.lib.umx_hip_stream_floats(self.h)
         self._check(self.lib.umx_hip_stream_set(self.h, a.ctypes.data_as(_fp)))
+
+    def track_stream_reset(self, track=-1):
+        self._check(self.lib.umx_hip_track_stream_reset(self.h, track))
+
+    def track_stream_get(self, track):
+        a = np.empty(self.lib.umx_hip_stream_floats(self.h), np.float32)
+        self._check(self.lib.umx_hip_track_stream_get(self.h, track, a.ctypes.data_as(_fp)))
+        return a
+
+    def track_stream_set(self, track, a):
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.size == self.lib.umx_hip_stream_floats(self.h)
+        self._check(self.lib.umx_hip_track_stream_set(self.h, track, a.ctypes.data_as(_fp)))
 
     def stream_get_layer(self, layer):
         """(h, c) of LSTM layer `layer`, all chains: [4 targets][2 dirs][2: h, c][hidden/2]."""
@@ -281,6 +321,43 @@ class Engine:
         self._check(self.lib.umx_hip_infer_segment(self.h, a.ctypes.data_as(_fp), n, arr, flags))
         return [np.ascontiguousarray(o.reshape(n, 2).T) for o in outs]
 
+    def infer_batch(self, waves, flags=0):
+        """waves: list (one per track lane) of (2,n_i) arrays or None (lane idle) -> list of [4 x (2,n_i)] or None."""
+        nb = len(waves)
+        aud, ns, outs = (C.c_void_p * nb)(), (C.c_int * nb)(), (C.c_void_p * (4 * nb))()
+        keep = []
+        for i, wv in enumerate(waves):
+            if wv is None:
+                aud[i], ns[i] = None, 0
+                continue
+            wv = np.asarray(wv, np.float32)
+            a = np.ascontiguousarray(wv.T).ravel()
+            o = [np.empty(2 * wv.shape[1], np.float32) for _ in range(4)]
+            keep.append((a, o))
+            aud[i], ns[i] = a.ctypes.data, wv.shape[1]
+            for t in range(4):
+                outs[4 * i + t] = o[t].ctypes.data
+        self._check(self.lib.umx_hip_infer_batch(self.h, nb, aud, ns, outs, flags))
+        res, k = [], 0
+        for wv in waves:
+            if wv is None:
+                res.append(None)
+                continue
+            n = keep[k][0].size // 2
+            res.append([np.ascontiguousarray(o.reshape(n, 2).T) for o in keep[k][1]])
+            k += 1
+        return res
+
+    def infer_batch_ptrs(self, audio_ptrs, ns, out_ptrs, flags=0, where="device"):
+        """Raw pointers: audio_ptrs[i] (0 = lane idle), ns[i], out_ptrs[4*i + t]; where = "device" (HBM buffers) or
+        "host_async" (host buffers, pinned for overlap: H2D + kernels + D2H queued).  Asynchronous: call sync()."""
+        nb = len(audio_ptrs)
+        aud = (C.c_void_p * nb)(*[p or None for p in audio_ptrs])
+        n_ = (C.c_int * nb)(*ns)
+        outs = (C.c_void_p * (4 * nb))(*[p or None for p in out_ptrs])
+        fn = self.lib.umx_hip_infer_batch_device if where == "device" else self.lib.umx_hip_infer_batch_async
+        self._check(fn(self.h, nb, aud, n_, outs, flags))
+
     def infer_segment_device(self, audio_ptr, n, out_ptrs, flags=0):
         """Raw device pointers (e.g. torch tensor .data_ptr()); asynchronous, call sync()."""
         arr = (C.c_void_p * 4)(*out_ptrs)
@@ -311,7 +388,7 @@ class Engine:
         if got != n:
             raise UmxError(ERR_HIP, f"tap {what!r} failed ({got})")
         T, H = self.T, self.hidden
-        what = what.split("@")[0]
+        what = what.split("@")[0].split("#")[0]
         if what in ("lstm_l0", "lstm_l1"):
             return buf.reshape(T, H)
         if what == "proj":
@@ -322,7 +399,7 @@ class Engine:
             return buf.reshape(2, T, NB)
         if what == "x":
             return buf.reshape(T, KX)
-        if what in ("fc1", "lstm"):
+        if what in ("fc1", "lstm", "fc2"):
             return buf.reshape(T, H)
         if what == "mask":
             return buf.reshape(T, NOUT)

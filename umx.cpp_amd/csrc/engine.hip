@@ -3,7 +3,9 @@
 //   stft -> |.| / crop+stack -> 4 x [fc1 bn tanh -> 3-layer BiLSTM -> fc2 bn relu -> fc3 bn scale
 //   relu -> mask*mix] -> Wiener EM -> 4 x istft
 // The four targets run inside the same launches; consecutive segments alternate between two pipeline
-// slots (streams) so that their LSTM layers overlap as an exact wavefront (see struct Slot).  Also here: the
+// slots (streams) so that their LSTM layers overlap as an exact wavefront (see struct Slot).  A context created
+// for several tracks (umx_hip_create_tracks) runs one segment of each track per call: every stage is queued for
+// all track lanes, and the LSTM recurrence of all lanes is ONE launch (lstm_batch.h).  Also here: the
 // whole-track drivers (split / shift inference with the track resident in HBM), the phased form of a segment
 // for the multi-GPU state-carry mode, weight residency (u8/u16 as stored, or expanded) and the GEMM flavour.
 #include "../../include/umx_hip.h"
@@ -22,7 +24,7 @@
 #include "gemm_kernels.h"
 #include "gemm_bf16x3.h"
 #include "lstm_kernels.h"
-#include "lstm_wavefront.h"
+#include "lstm_batch.h"
 #include "track_kernels.h"
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
@@ -78,28 +80,63 @@ enum
 const char *kStageNames[ST_COUNT] = {"stft",  "fc1", "lstm_ih0", "lstm_rec0", "lstm_ih1", "lstm_rec1", "lstm_ih2",
                                      "lstm_rec2", "fc2", "fc3_mask", "wiener",  "istft",    "ola"};
 
-// One pipeline slot = everything one in-flight segment needs.  Two slots on two streams let segment
-// s+1 run its STFT/GEMMs and LSTM layer l while segment s is in layer l+1 (the exact wavefront of
-// R_l(s+1) waits only for R_l(s) through an event); the LSTM kernels are latency-bound
+// One track lane of a pipeline slot = the activations of one in-flight segment of one track.
+struct Lane
+{
+    TargetAct ta[4];
+    float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
+    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr;
+    unsigned *maxabs = nullptr;
+};
+
+// One pipeline slot = everything one in-flight segment (of every track lane) needs.  Two slots on two streams let
+// segment s+1 run its STFT/GEMMs and LSTM layer l while segment s is in layer l+1 (the exact wavefront of
+// R_l(s+1) waits only for R_l(s) through an event); the single-track LSTM kernels are latency-bound
 // and use half of each CU's wave slots, so two of them co-reside and fill each other's hand-off gaps.
 struct Slot
 {
     hipStream_t stream = nullptr;
-    TargetAct ta[4];
-    float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
-    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr, *hbuf = nullptr;
-    unsigned *maxabs = nullptr, *status = nullptr, *lsync = nullptr;
+    Lane lane[LSTMB_MAX_TRACKS];
+    float *hbuf = nullptr;
+    unsigned *status = nullptr, *lsync = nullptr;
     unsigned long long *lprof = nullptr;
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t rec_done[3] = {}; // LSTM layer l of this slot's segment has finished (state updated)
-    hipEvent_t front_done = nullptr, back_done = nullptr; // wavefront mode
     bool have_times = false, last_persistent = false, used = false;
-    // wavefront mode: the segment living in this slot
-    float *job_out[4] = {};
-    int job_n = 0, job_stage = -1; // -1 free, l = waiting for LSTM layer l (0..2)
-    unsigned job_flags = 0;
+    unsigned bepoch = 0; // batched LSTM launches on this slot's granule area since it was last cleared
 };
 } // namespace
+
+// kernel instantiation pickers
+static const void *lstm_persistent_fn(int kpw, bool precise)
+{
+    return precise ? (kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, true>)
+                      : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, true>)
+                      : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, true>)
+                                  : reinterpret_cast<const void *>(lstm_persistent_kernel<64, true>))
+                   : (kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, false>)
+                      : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, false>)
+                      : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, false>)
+                                  : reinterpret_cast<const void *>(lstm_persistent_kernel<64, false>));
+}
+template <int HL> static const void *lstm_batch_fn_hl(bool wq, bool precise)
+{
+    return wq ? (precise ? reinterpret_cast<const void *>(lstm_batch_kernel<HL, true, true>)
+                         : reinterpret_cast<const void *>(lstm_batch_kernel<HL, true, false>))
+              : (precise ? reinterpret_cast<const void *>(lstm_batch_kernel<HL, false, true>)
+                         : reinterpret_cast<const void *>(lstm_batch_kernel<HL, false, false>));
+}
+static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
+{
+    switch (Hl)
+    {
+    case 64: return lstm_batch_fn_hl<64>(wq, precise);
+    case 128: return lstm_batch_fn_hl<128>(wq, precise);
+    case 256: return lstm_batch_fn_hl<256>(wq, precise);
+    case 512: return lstm_batch_fn_hl<512>(wq, precise);
+    default: return nullptr;
+    }
+}
 
 struct umx_hip_ctx
 {
@@ -110,26 +147,25 @@ struct umx_hip_ctx
     float *whh[3] = {}, *bhh[3] = {};
     float *window = nullptr, *nw = nullptr;
     float2 *tw1 = nullptr, *tw2 = nullptr;
-    float *audio_in = nullptr, *out_dev[4] = {};
+    float *audio_in = nullptr, *out_dev[4] = {}; // device staging of the phased (multi-GPU carry) entry points
+    float *stage_in[2] = {}, *stage_out[2][4 * LSTMB_MAX_TRACKS] = {}; // per pipeline slot: device staging of the host-pointer
+    int ensure_staging();                                              // entry points, [lane] / [lane][4]; allocated on first use
+    hipEvent_t order_ev = nullptr;
     float *state = nullptr;
-    Slot slot[3];             // 2 used in "slots" mode, 3 in "wavefront" mode
+    Slot slot[2];
     int nslots = 2;
-    bool wavefront = false;   // one fused LSTM launch per segment for 3 consecutive segments (Hl = 512)
-    bool last_was_wavefront = false;
-    hipStream_t main_stream = nullptr, back_stream = nullptr; // wavefront mode (front work runs on slot.stream)
-    hipEvent_t lstm_ev[3] = {};
-    long long nlaunch = 0;
+    int B = 1;                // track lanes (umx_hip_create_tracks); every lane has its own streaming LSTM state
+    bool lstm_batched = false; // LSTM recurrence on the matrix cores for all lanes at once (lstm_batch.h); fixed at
+                               // create so that a track's bits never depend on how many lanes a call uses
     unsigned tag_epoch = 0;   // persistent LSTM launches so far (granule tags are unique per launch)
     unsigned next_tag_base()
     {
         // 4096 tags per launch (T + 1 <= 4096 is checked at create); wraps after ~1M launches, where one
         // stale line from exactly 2^20 launches ago would have to survive in an L2 -- every buffer is
-        // zeroed at that point anyway (see run_lstm_layer / wf_launch)
+        // zeroed at that point anyway (see run_lstm_layer)
         tag_epoch = (tag_epoch + 1) & 0xFFFFF;
         return tag_epoch << 12;
     }
-    unsigned *wf_sync = nullptr, *wf_status = nullptr;
-    size_t wf_sync_words = 0;
     int cur = 0;              // slot of the most recently queued segment
     long long nseg = 0;       // segments queued since creation
     size_t lsync_words = 0;
@@ -160,12 +196,16 @@ struct umx_hip_ctx
         return UMX_OK;
     }
     int init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors,
-             unsigned create_flags);
+             unsigned create_flags, int n_tracks);
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
     bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
     unsigned char *whh_q[3] = {}; // u8-resident W_hh (create flag), same layout as whh[]
     float whh_s[3][8] = {}, whh_o[3][8] = {};
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
+    // one segment of each of `nb` track lanes (lane i = track i of this context; audio[i] == nullptr: lane idle)
+    int infer_batch(int nb, const float *const *audio_dev, const int *n, float *const *out /* [nb][4] */, unsigned flags);
+    int lstm_batch_capacity = 0; // co-resident workgroups of the batched LSTM kernel
+    size_t state_floats() const { return (size_t)4 * 12 * Hl; }
     // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
     // whole track on the device (split_inference / shift_inference, umx.cpp:99-295)
     int track(const float *audio_host, int length, int shift_offset, float *const out_host[4], unsigned flags,
@@ -179,14 +219,13 @@ struct umx_hip_ctx
     int ph_next = -1; // -1: no phased segment open; 0..2: next LSTM layer; 3: back stage pending
     int ph_n = 0;
     unsigned ph_flags = 0;
-    int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise);
+    int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask);
+    int run_lstm_layer_batched(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask);
     int sync_all();
-    void launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
-    int stage_front(Slot &sl, hipStream_t st, const float *audio_dev, int n, const int *active, int nact);
-    int stage_back(Slot &sl, hipStream_t st, float *const out[4], int n, unsigned flags, const int *active, int nact);
-    int wf_enqueue(const float *audio_dev, int n, float *const out[4], unsigned flags);
-    int wf_launch(bool new_segment);
-    int wf_flush();
+    void launch_gemm(Lane &ln, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
+    int stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active, int nact);
+    int stage_back(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n,
+                   unsigned flags, const int *active, int nact);
     static void active_list(unsigned flags, int *active, int &nact)
     {
         nact = 0;
@@ -229,8 +268,15 @@ bool dequant(const umx_tensor_view &tv, size_t expect, std::vector<float> &out)
 } // namespace
 
 int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_tensor_view *tensors, int n_tensors,
-                      unsigned create_flags)
+                      unsigned create_flags, int n_tracks)
 {
+    if (n_tracks < 1 || n_tracks > LSTMB_MAX_TRACKS)
+    {
+        set_error("n_tracks must be in [1, 16]");
+        return UMX_ERR_ARG;
+    }
+    B = n_tracks;
+    lstm_batched = B > 1 || (create_flags & UMX_CREATE_LSTM_BATCHED);
     if (hidden <= 0 || hidden % 128 != 0 || hidden > 2048)
     {
         set_error("hidden_size must be a positive multiple of 128 (<= 2048)");
@@ -584,60 +630,67 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         if (int rc = upload(&tw2, t2))
             return rc;
     }
-    // ---- per-segment buffers: two pipeline slots
+    // ---- per-segment buffers: two pipeline slots x B track lanes
     if (int rc = dalloc(&audio_in, (size_t)2 * N))
         return rc;
     for (int k = 0; k < 4; ++k)
         if (int rc = dalloc(&out_dev[k], (size_t)2 * N))
             return rc;
-    if (int rc = dalloc(&state, (size_t)4 * 12 * Hl))
+    if (int rc = dalloc(&state, state_floats() * B))
         return rc;
-    lsync_words = LSTM_SYNC_HEADER_WORDS + granule_count(S) * 2;
+    lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) : (size_t)0);
     if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
         lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
-    // default: two pipeline slots with one LSTM launch per layer ("slots").  UMX_PIPELINE=wavefront selects
-    // the fused three-segment LSTM launches of lstm_wavefront.h (Hl = 512 only; exact but measured slower)
-    wavefront = false;
-    if (const char *e = getenv("UMX_PIPELINE"))
-        if (std::string(e) == "wavefront" && Hl == LSTM_WF_HL && !whh_q[0]) // (the experiment knows fp32 W_hh only)
-            wavefront = true;
-    nslots = wavefront ? 3 : 2;
+    nslots = 2;
     for (int si = 0; si < nslots; ++si)
     {
         Slot &sl = slot[si];
         UMX_HIP_CHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         for (int tg = 0; tg < 4; ++tg)
         {
-            TargetAct &b = sl.ta[tg];
-            if (int rc = dalloc(&b.cat, (size_t)Tp * 2 * H))
+            // what the batched LSTM launch reads / writes for every lane sits at a constant lane stride
+            float *cat_all = nullptr, *la_all = nullptr, *lb_all = nullptr, *P_all = nullptr;
+            if (int rc = dalloc(&cat_all, (size_t)B * Tp * 2 * H))
                 return rc;
-            if (int rc = dalloc(&b.la, (size_t)Tp * H))
+            if (int rc = dalloc(&la_all, (size_t)B * Tp * H))
                 return rc;
-            if (int rc = dalloc(&b.lb, (size_t)Tp * H))
+            if (int rc = dalloc(&lb_all, (size_t)B * Tp * H))
                 return rc;
-            if (int rc = dalloc(&b.P, (size_t)Tp * 4 * H))
+            if (int rc = dalloc(&P_all, (size_t)B * Tp * 4 * H))
                 return rc;
-            if (int rc = dalloc(&b.a2, (size_t)Tp * H))
+            for (int ln = 0; ln < B; ++ln)
+            {
+                TargetAct &b = sl.lane[ln].ta[tg];
+                b.cat = cat_all + (size_t)ln * Tp * 2 * H;
+                b.la = la_all + (size_t)ln * Tp * H;
+                b.lb = lb_all + (size_t)ln * Tp * H;
+                b.P = P_all + (size_t)ln * Tp * 4 * H;
+                if (int rc = dalloc(&b.a2, (size_t)Tp * H))
+                    return rc;
+                if (int rc = dalloc(&b.mag, (size_t)2 * T * NBINS))
+                    return rc;
+            }
+        }
+        for (int ln = 0; ln < B; ++ln)
+        {
+            Lane &L = sl.lane[ln];
+            if (int rc = dalloc(&L.spec, (size_t)2 * T * NBINS))
                 return rc;
-            if (int rc = dalloc(&b.mag, (size_t)2 * T * NBINS))
+            if (int rc = dalloc(&L.mix_mag, (size_t)2 * T * NBINS))
+                return rc;
+            if (int rc = dalloc(&L.x, (size_t)Tp * KX))
+                return rc;
+            if (int rc = dalloc(&L.y, (size_t)4 * 2 * T * NBINS))
+                return rc;
+            if (int rc = dalloc(&L.frames, (size_t)4 * T * NFFT))
+                return rc;
+            if (int rc = dalloc(&L.wpart, (size_t)4 * nbatch * NBINS * 9))
+                return rc;
+            if (int rc = dalloc(&L.R, (size_t)4 * NBINS * 8))
+                return rc;
+            if (int rc = dalloc(&L.maxabs, 4))
                 return rc;
         }
-        if (int rc = dalloc(&sl.spec, (size_t)2 * T * NBINS))
-            return rc;
-        if (int rc = dalloc(&sl.mix_mag, (size_t)2 * T * NBINS))
-            return rc;
-        if (int rc = dalloc(&sl.x, (size_t)Tp * KX))
-            return rc;
-        if (int rc = dalloc(&sl.y, (size_t)4 * 2 * T * NBINS))
-            return rc;
-        if (int rc = dalloc(&sl.frames, (size_t)4 * T * NFFT))
-            return rc;
-        if (int rc = dalloc(&sl.wpart, (size_t)4 * nbatch * NBINS * 9))
-            return rc;
-        if (int rc = dalloc(&sl.R, (size_t)4 * NBINS * 8))
-            return rc;
-        if (int rc = dalloc(&sl.maxabs, 4))
-            return rc;
         if (int rc = dalloc(&sl.status, 4))
             return rc;
         if (int rc = dalloc(&sl.hbuf, (size_t)2 * 8 * Hl))
@@ -650,44 +703,46 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             UMX_HIP_CHECK(hipEventCreate(&sl.ev[i]));
         for (int l = 0; l < 3; ++l)
             UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.rec_done[l], hipEventDisableTiming));
-        UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming));
-        UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.back_done, hipEventDisableTiming));
-    }
-    if (wavefront)
-    {
-        UMX_HIP_CHECK(hipStreamCreateWithFlags(&main_stream, hipStreamNonBlocking));
-        UMX_HIP_CHECK(hipStreamCreateWithFlags(&back_stream, hipStreamNonBlocking));
-        if (const char *e = getenv("UMX_WF_ONE_STREAM")) // debugging: no concurrency between stages
-            if (atoi(e))
-            {
-                back_stream = main_stream;
-                for (int si = 0; si < 3; ++si)
-                    slot[si].stream = main_stream;
-            }
-        for (int i = 0; i < 3; ++i)
-            UMX_HIP_CHECK(hipEventCreateWithFlags(&lstm_ev[i], hipEventDisableTiming));
-        wf_sync_words = LSTM_SYNC_HEADER_WORDS + 3 * granule_count(S) * 2;
-        if (int rc = dalloc(&wf_sync, wf_sync_words))
-            return rc;
-        if (int rc = dalloc(&wf_status, 4))
-            return rc;
     }
     stream = slot[0].stream;
     {
-        // residency of the persistent LSTM kernel (all instantiations have the same footprint class;
-        // take the one this hidden size uses)
+        // residency of the persistent LSTM kernel: the smaller of the two activation flavours of the
+        // instantiation this hidden size uses (the two-grid co-residency of the pipeline rests on it)
         const int kpw = Hl / 8;
-        const void *fn = kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, false>)
-                         : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, false>)
-                         : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, false>)
-                                     : reinterpret_cast<const void *>(lstm_persistent_kernel<64, false>);
-        int per_cu = 0, cus = 0;
-        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, lstm_threads, 0));
+        int per_cu = 1 << 30, cus = 0;
+        for (int precise = 0; precise < 2; ++precise)
+        {
+            const void *fn = lstm_persistent_fn(kpw, precise != 0);
+            int v = 0;
+            UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, lstm_threads, 0));
+            per_cu = std::min(per_cu, v);
+        }
         UMX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         lstm_capacity = per_cu * cus;
         if (const char *e = getenv("UMX_LSTM_NO_OVERLAP")) // testing: never run two LSTM grids at once
             if (atoi(e))
                 lstm_capacity = std::min(lstm_capacity, 2 * 8 * S - 1);
+        if (lstm_batched)
+        {
+            // the batched kernel: worst-case dynamic LDS (16 lanes), both activation flavours
+            const size_t lds_max = lstmb_lds_bytes(LSTMB_MAX_TRACKS, 8);
+            per_cu = 1 << 30;
+            for (int precise = 0; precise < 2; ++precise)
+                for (int wq = 0; wq < 2; ++wq)
+                {
+                    const void *fn = lstm_batch_fn(Hl, wq != 0, precise != 0);
+                    if (!fn)
+                    {
+                        set_error("track batching needs hidden_size in {128, 256, 512, 1024}");
+                        return UMX_ERR_ARG;
+                    }
+                    UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+                    int v = 0;
+                    UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstmb_lds_bytes(B > 8 ? 16 : B > 4 ? 8 : B > 2 ? 4 : B > 1 ? 2 : 1, B > 8 ? 8 : 16)));
+                    per_cu = std::min(per_cu, v);
+                }
+            lstm_batch_capacity = per_cu * cus;
+        }
     }
     // dynamic LDS > 64 KiB must be opted into
     {
@@ -716,23 +771,33 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     return UMX_OK;
 }
 
+int umx_hip_ctx::ensure_staging()
+{
+    if (stage_in[0])
+        return UMX_OK;
+    for (int si = 0; si < 2; ++si)
+    {
+        if (int rc = dalloc(&stage_in[si], (size_t)2 * N * B, false))
+            return rc;
+        for (int k = 0; k < 4 * B; ++k)
+            if (int rc = dalloc(&stage_out[si][k], (size_t)2 * N, false))
+                return rc;
+    }
+    return UMX_OK;
+}
+
 int umx_hip_ctx::sync_all()
 {
-    if (wavefront)
-    {
-        if (int rc = wf_flush())
-            return rc;
-        UMX_HIP_CHECK(hipStreamSynchronize(main_stream));
-        UMX_HIP_CHECK(hipStreamSynchronize(back_stream));
-    }
     for (int si = 0; si < nslots; ++si)
         UMX_HIP_CHECK(hipStreamSynchronize(slot[si].stream));
     return UMX_OK;
 }
 
 // ---------------------------------------------------------------- LSTM layer
-int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise)
+int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask)
 {
+    if (lstm_batched)
+        return run_lstm_layer_batched(sl, layer, active, nact, stepwise, lane_mask);
     hipStream_t st = sl.stream;
     LstmArgs a;
     memset(&a, 0, sizeof a);
@@ -757,7 +822,7 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
     a.layer = layer;
     for (int i = 0; i < 4; ++i)
     {
-        const TargetAct &b = sl.ta[i];
+        const TargetAct &b = sl.lane[0].ta[i];
         a.P[i] = b.P;
         if (layer == 0)
         {
@@ -791,16 +856,7 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
         // census + arrival counter every launch; the granule area only when the tag epoch wraps
         UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (tag_epoch == 0 ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
         void *kargs[] = {&a};
-        const bool precise = last_flags & UMX_FLAG_PRECISE_ACT;
-        const void *fn =
-            precise ? (kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, true>)
-                       : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, true>)
-                       : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, true>)
-                                   : reinterpret_cast<const void *>(lstm_persistent_kernel<64, true>))
-                    : (kpw == 8    ? reinterpret_cast<const void *>(lstm_persistent_kernel<8, false>)
-                       : kpw == 16 ? reinterpret_cast<const void *>(lstm_persistent_kernel<16, false>)
-                       : kpw == 32 ? reinterpret_cast<const void *>(lstm_persistent_kernel<32, false>)
-                                   : reinterpret_cast<const void *>(lstm_persistent_kernel<64, false>));
+        const void *fn = lstm_persistent_fn(kpw, last_flags & UMX_FLAG_PRECISE_ACT);
         // The granule exchange needs the whole grid co-resident.  Residency was checked against the
         // occupancy of this kernel at create time (lstm_capacity); a plain launch is used because ROCm
         // serialises cooperative launches against other queues, which would defeat the two-slot overlap.
@@ -832,8 +888,95 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
     return UMX_OK;
 }
 
+// All track lanes of `lane_mask` through ONE launch per layer (lstm_batch.h).  stepwise (or a grid that cannot be
+// co-resident): the same kernel one step per launch, carried through the fp32 stream state -- bit-identical.
+int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask)
+{
+    hipStream_t st = sl.stream;
+    LstmBArgs a;
+    memset(&a, 0, sizeof a);
+    a.W = whh[layer];
+    a.Wq = whh_q[layer];
+    for (int c = 0; c < 8; ++c)
+    {
+        a.wsc[c] = whh_s[layer][c];
+        a.wof[c] = whh_o[layer][c];
+    }
+    a.bhh = bhh[layer];
+    a.state = state;
+    a.state_stride = state_floats();
+    a.sync = sl.lsync;
+    a.status = sl.status;
+    a.prof = (last_flags & UMX_FLAG_LSTM_PROFILE) ? sl.lprof : nullptr;
+    a.force_safe = (last_flags & UMX_FLAG_LSTM_FORCE_SAFE) ? 1 : 0;
+    a.Hl = Hl;
+    a.S = S;
+    a.T = T;
+    a.ldp = 4 * H;
+    a.layer = layer;
+    a.p_stride = (size_t)Tp * 4 * H;
+    a.out_stride = layer == 2 ? (size_t)Tp * 2 * H : (size_t)Tp * H;
+    a.ldo = layer == 2 ? 2 * H : H;
+    a.col0 = layer == 2 ? H : 0; // inference.cpp:118-123 skip concat: lstm output -> right half of cat
+    for (int i = 0; i < 4; ++i)
+    {
+        const TargetAct &b = sl.lane[0].ta[i];
+        a.P[i] = b.P;
+        a.out[i] = layer == 0 ? b.la : layer == 1 ? b.lb : b.cat;
+        a.tmap[i] = i < nact ? active[i] : 0;
+    }
+    a.nchains = 2 * nact;
+    a.lane_mask = lane_mask;
+    int top = 0;
+    for (int ln = 0; ln < LSTMB_MAX_TRACKS; ++ln)
+        if ((lane_mask >> ln) & 1u)
+            top = ln + 1;
+    a.nbp = top > 8 ? 16 : top > 4 ? 8 : top > 2 ? 4 : top > 1 ? 2 : 1;
+    a.bulk = a.nbp > 8 ? 8 : 16;
+    const size_t lds = lstmb_lds_bytes(a.nbp, a.bulk);
+    const bool wq = whh_q[layer] != nullptr;
+    const void *fn = lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
+    void *kargs[] = {&a};
+    bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
+    if (persistent)
+    {
+        // 4 tag bits of epoch, counted per slot (= per granule area): the area is zeroed whenever the count wraps, so
+        // between two clears no two launches on it share an epoch (a lane or chain that sat out some launches keeps
+        // its old granules, and they must never pass for a later launch's)
+        sl.bepoch = (sl.bepoch + 1) & 15u;
+        const bool clear = sl.bepoch == 0;
+        if (clear)
+            sl.bepoch = 1;
+        a.tag_epoch = sl.bepoch;
+        a.t_begin = 0;
+        a.t_end = T;
+        a.census = 1;
+        UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (clear ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
+        hipError_t e = hipLaunchKernel(fn, dim3(8 * S), dim3(LSTM_THREADS), kargs, lds, st);
+        if (e != hipSuccess)
+        {
+            (void)hipGetLastError();
+            persistent_ok = false;
+            persistent = false;
+        }
+    }
+    if (!persistent)
+    {
+        a.census = 0;
+        for (int step = 0; step < T; ++step)
+        {
+            a.t_begin = step;
+            a.t_end = step + 1;
+            UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * S), dim3(LSTM_THREADS), kargs, lds, st));
+        }
+    }
+    sl.last_persistent = persistent;
+    UMX_HIP_CHECK(hipGetLastError());
+    return UMX_OK;
+}
+
 // ---------------------------------------------------------------- stages of one segment
-void umx_hip_ctx::launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg)
+void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg)
 {
     GemmArgs g;
     memset(&g, 0, sizeof g);
@@ -938,317 +1081,145 @@ void umx_hip_ctx::launch_gemm(Slot &sl, hipStream_t st, int mode, int layer, con
 #undef UMX_LAUNCH
 }
 
-// stft -> |.|, crop/stack -> fc1/bn1/tanh -> input projection of LSTM layer 0
-int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, const float *audio_dev, int n, const int *active, int nact)
+// stft -> |.|, crop/stack -> fc1/bn1/tanh -> input projection of LSTM layer 0; stage by stage over the track lanes
+int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active,
+                             int nact)
 {
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_STFT], st));
-    UMX_HIP_CHECK(hipMemsetAsync(sl.maxabs, 0, sizeof(unsigned), st));
-    hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev, n, N, T, window, tw1, tw2, sl.spec,
-                       sl.mix_mag, sl.x, sl.maxabs);
+    for (int ln = 0; ln < nb; ++ln)
+        if (audio_dev[ln])
+        {
+            Lane &L = sl.lane[ln];
+            UMX_HIP_CHECK(hipMemsetAsync(L.maxabs, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev[ln], n[ln], N, T, window, tw1, tw2, L.spec,
+                               L.mix_mag, L.x, L.maxabs);
+        }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
     if (nact > 0)
-    {
-        launch_gemm(sl, st, G_FC1, 0, active, nact, false);
-        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
-        launch_gemm(sl, st, G_IH, 0, active, nact, false);
-    }
-    else
-        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
+        for (int ln = 0; ln < nb; ++ln)
+            if (audio_dev[ln])
+                launch_gemm(sl.lane[ln], st, G_FC1, 0, active, nact, false);
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
+    if (nact > 0)
+        for (int ln = 0; ln < nb; ++ln)
+            if (audio_dev[ln])
+                launch_gemm(sl.lane[ln], st, G_IH, 0, active, nact, false);
     return UMX_OK;
 }
 
 // fc2/bn2/relu -> fc3/bn3/scale/relu/mask -> Wiener (or mix phase) -> iSTFT -> overlap-add
-int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, float *const out[4], int n, unsigned flags, const int *active,
-                            int nact)
+int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n,
+                            unsigned flags, const int *active, int nact)
 {
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
     if (nact > 0)
-    {
-        launch_gemm(sl, st, G_FC2, 0, active, nact, dbg);
-        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
-        launch_gemm(sl, st, G_FC3, 0, active, nact, dbg);
-    }
-    else
-        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
-    for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
-        if (flags & UMX_FLAG_SKIP_TARGET(tg))
-            UMX_HIP_CHECK(hipMemsetAsync(sl.ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
+        for (int ln = 0; ln < nb; ++ln)
+            if (audio_dev[ln])
+                launch_gemm(sl.lane[ln], st, G_FC2, 0, active, nact, dbg);
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
+    if (nact > 0)
+        for (int ln = 0; ln < nb; ++ln)
+            if (audio_dev[ln])
+                launch_gemm(sl.lane[ln], st, G_FC3, 0, active, nact, dbg);
+    for (int ln = 0; ln < nb; ++ln)
+        if (audio_dev[ln])
+            for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
+                if (flags & UMX_FLAG_SKIP_TARGET(tg))
+                    UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_WIENER], st));
-    WienerMags wm;
-    for (int s = 0; s < 4; ++s)
-        wm.m[s] = sl.ta[s].mag;
     const int bt = (NBINS + 255) / 256;
-    if (flags & UMX_FLAG_NO_WIENER)
+    for (int ln = 0; ln < nb; ++ln)
     {
-        const size_t nel = (size_t)2 * T * NBINS;
-        hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, sl.spec, wm, T, sl.y);
-    }
-    else
-    {
-        hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, sl.spec, wm, T, sl.maxabs,
-                           sl.wpart, nbatch);
-        hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, sl.wpart, nbatch, sl.R);
-        hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, sl.spec, wm, T, sl.maxabs, sl.R, sl.y);
+        if (!audio_dev[ln])
+            continue;
+        Lane &L = sl.lane[ln];
+        WienerMags wm;
+        for (int s = 0; s < 4; ++s)
+            wm.m[s] = L.ta[s].mag;
+        if (flags & UMX_FLAG_NO_WIENER)
+        {
+            const size_t nel = (size_t)2 * T * NBINS;
+            hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, L.spec, wm, T, L.y);
+        }
+        else
+        {
+            hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.wpart,
+                               nbatch);
+            hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, nbatch, L.R);
+            hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
+        }
     }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
-    hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, sl.y, T, window, nw, tw1, tw2, sl.frames);
+    for (int ln = 0; ln < nb; ++ln)
+        if (audio_dev[ln])
+            hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, sl.lane[ln].y, T, window, nw, tw1, tw2,
+                               sl.lane[ln].frames);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
-    OlaOut oo;
-    for (int s = 0; s < 4; ++s)
-        oo.p[s] = out[s];
-    hipLaunchKernelGGL(istft_ola_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, st, sl.frames, T, n, oo);
+    for (int ln = 0; ln < nb; ++ln)
+        if (audio_dev[ln])
+        {
+            OlaOut oo;
+            for (int s = 0; s < 4; ++s)
+                oo.p[s] = out[4 * ln + s];
+            hipLaunchKernelGGL(istft_ola_kernel, dim3((n[ln] + 255) / 256, 4), dim3(256), 0, st, sl.lane[ln].frames, T, n[ln], oo);
+        }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_COUNT], st));
     UMX_HIP_CHECK(hipGetLastError());
     sl.have_times = true;
     return UMX_OK;
 }
 
-// ---------------------------------------------------------------- wavefront mode (Hl = 512)
-// Segment k lives in slot k % 3.  One fused LSTM launch per queued segment advances
-//   R_0(k), R_1(k-1), R_2(k-2)
-// (lstm_wavefront_kernel); between launches the main stream runs the input projections that depend on the
-// layer outputs just produced (I_1(k), I_2(k-1)); the front of the next segment runs on its slot's stream
-// and the back of segment k-2 on the back stream, both overlapping the next LSTM launch.  umx_hip_sync
-// drains the wavefront with the partial launches {R_1, R_2} and {R_2}.
-int umx_hip_ctx::wf_launch(bool new_segment)
-{
-    (void)new_segment;
-    // jobs by LSTM stage
-    Slot *by_stage[3] = {nullptr, nullptr, nullptr};
-    for (int si = 0; si < 3; ++si)
-        if (slot[si].job_stage >= 0 && slot[si].job_stage <= 2)
-            by_stage[slot[si].job_stage] = &slot[si];
-    int mask = 0;
-    for (int l = 0; l < 3; ++l)
-        if (by_stage[l])
-            mask |= 1 << l;
-    if (!mask)
-        return UMX_OK;
-    Slot *any = by_stage[0] ? by_stage[0] : by_stage[1] ? by_stage[1] : by_stage[2];
-    const unsigned flags = any->job_flags;
-    int active[4], nact;
-    active_list(flags, active, nact);
-    hipStream_t st = main_stream;
-    if (nact > 0)
-    {
-        LstmWaveArgs a;
-        memset(&a, 0, sizeof a);
-        a.state = state;
-        a.sync = wf_sync;
-        a.status = wf_status;
-        a.S = S;
-        a.T = T;
-        a.ldp = 4 * H;
-        a.nchains = 2 * nact;
-        a.force_safe = (flags & UMX_FLAG_LSTM_FORCE_SAFE) ? 1 : 0;
-        a.prof = (flags & UMX_FLAG_LSTM_PROFILE) ? slot[0].lprof : nullptr;
-        for (int i = 0; i < 4; ++i)
-            a.tmap[i] = i < nact ? active[i] : 0;
-        for (int l = 0; l < 3; ++l)
-        {
-            LstmSet &q = a.set[l];
-            q.layer = l;
-            q.gran_off = (unsigned)(l * granule_count(S));
-            q.W = whh[l];
-            q.bhh = bhh[l];
-            if (!by_stage[l])
-                continue;
-            q.active = 1;
-            Slot &sl = *by_stage[l];
-            for (int i = 0; i < 4; ++i)
-            {
-                const TargetAct &b = sl.ta[i];
-                q.P[i] = b.P;
-                q.out[i] = l == 0 ? b.la : l == 1 ? b.lb : b.cat; // inference.cpp:118-123: layer 2 -> right half of cat
-            }
-            q.ldo = l == 2 ? 2 * H : H;
-            q.col0 = l == 2 ? H : 0;
-        }
-        if (by_stage[0])
-            UMX_HIP_CHECK(hipStreamWaitEvent(st, by_stage[0]->front_done, 0));
-        a.tag_base = next_tag_base();
-        UMX_HIP_CHECK(hipMemsetAsync(wf_sync, 0, sizeof(unsigned) * (tag_epoch == 0 ? wf_sync_words : LSTM_SYNC_HEADER_WORDS), st));
-        void *kargs[] = {&a};
-        const bool pr = flags & UMX_FLAG_PRECISE_ACT;
-        const void *fn = nullptr;
-#define UMX_WF(M) (pr ? reinterpret_cast<const void *>(lstm_wavefront_kernel<M, true>) : reinterpret_cast<const void *>(lstm_wavefront_kernel<M, false>))
-        switch (mask)
-        {
-        case 1: fn = UMX_WF(1); break;
-        case 2: fn = UMX_WF(2); break;
-        case 3: fn = UMX_WF(3); break;
-        case 4: fn = UMX_WF(4); break;
-        case 5: fn = UMX_WF(5); break;
-        case 6: fn = UMX_WF(6); break;
-        default: fn = UMX_WF(7); break;
-        }
-#undef UMX_WF
-        for (int l = 0; l < 3; ++l)
-            if (by_stage[l])
-                UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_LSTM0 + 2 * l], st));
-        if (getenv("UMX_WF_SYNC_LAUNCH"))
-            (void)hipDeviceSynchronize();
-        UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(8 * S), dim3(LSTM_THREADS), kargs, 0, st));
-        if (getenv("UMX_WF_SYNC_LAUNCH") && atoi(getenv("UMX_WF_SYNC_LAUNCH")) > 1)
-            (void)hipDeviceSynchronize();
-        // input projections that consume the layer outputs just produced
-        for (int l = 0; l < 2; ++l)
-            if (by_stage[l])
-            {
-                UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_IH0 + 2 * (l + 1)], st));
-                launch_gemm(*by_stage[l], st, G_IH, l + 1, active, nact, false);
-            }
-        for (int l = 0; l < 3; ++l)
-            if (by_stage[l])
-                by_stage[l]->last_persistent = true;
-    }
-    else
-    {
-        if (by_stage[0])
-            UMX_HIP_CHECK(hipStreamWaitEvent(st, by_stage[0]->front_done, 0));
-        for (int l = 0; l < 3; ++l)
-            if (by_stage[l])
-            {
-                UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_LSTM0 + 2 * l], st));
-                if (l < 2)
-                    UMX_HIP_CHECK(hipEventRecord(by_stage[l]->ev[ST_IH0 + 2 * (l + 1)], st));
-            }
-    }
-    hipEvent_t done = lstm_ev[nlaunch % 3];
-    ++nlaunch;
-    UMX_HIP_CHECK(hipEventRecord(done, st));
-    if (getenv("UMX_WF_DEBUG_STATE"))
-    {
-        (void)hipDeviceSynchronize();
-        std::vector<float> hs((size_t)4 * 12 * Hl);
-        (void)hipMemcpy(hs.data(), state, hs.size() * sizeof(float), hipMemcpyDeviceToHost);
-        fprintf(stderr, "[wf] launch %lld mask %d state checksums (target 1):", nlaunch, mask);
-        for (int l = 0; l < 3; ++l)
-            for (int d = 0; d < 2; ++d)
-                for (int hc = 0; hc < 2; ++hc)
-                {
-                    double acc = 0;
-                    const float *q = hs.data() + state_off(1, l, d, hc, Hl);
-                    for (int i = 0; i < Hl; ++i)
-                        acc += (double)q[i] * (i + 1);
-                    fprintf(stderr, " L%d%c%c=%.9g", l, d ? 'b' : 'f', hc ? 'c' : 'h', acc);
-                }
-        fprintf(stderr, "\n");
-    }
-    // the segment that just finished layer 2 goes to the back stream
-    if (by_stage[2])
-    {
-        Slot &sl = *by_stage[2];
-        UMX_HIP_CHECK(hipStreamWaitEvent(back_stream, done, 0));
-        int act2[4], n2;
-        active_list(sl.job_flags, act2, n2);
-        if (int rc = stage_back(sl, back_stream, sl.job_out, sl.job_n, sl.job_flags, act2, n2))
-            return rc;
-        UMX_HIP_CHECK(hipEventRecord(sl.back_done, back_stream));
-        sl.job_stage = -1;
-    }
-    if (by_stage[1])
-        by_stage[1]->job_stage = 2;
-    if (by_stage[0])
-        by_stage[0]->job_stage = 1;
-    UMX_HIP_CHECK(hipGetLastError());
-    return UMX_OK;
-}
-
-int umx_hip_ctx::wf_flush()
-{
-    for (int guard = 0; guard < 4; ++guard)
-    {
-        bool pending = false;
-        for (int si = 0; si < 3; ++si)
-            pending = pending || slot[si].job_stage >= 0;
-        if (!pending)
-            return UMX_OK;
-        if (int rc = wf_launch(false))
-            return rc;
-    }
-    return UMX_OK;
-}
-
-int umx_hip_ctx::wf_enqueue(const float *audio_dev, int n, float *const out[4], unsigned flags)
-{
-    // a change of the target set / protocol flags cannot share a fused launch: drain first
-    const unsigned key_mask = 0xF00u | UMX_FLAG_LSTM_FORCE_SAFE | UMX_FLAG_PRECISE_ACT;
-    for (int si = 0; si < 3; ++si)
-        if (slot[si].job_stage >= 0 && ((slot[si].job_flags ^ flags) & key_mask))
-        {
-            if (int rc = wf_flush())
-                return rc;
-            break;
-        }
-    const int si = (int)(nseg % 3);
-    Slot &sl = slot[si];
-    if (sl.job_stage >= 0) // cannot happen: a slot is drained two launches after it was filled
-    {
-        set_error("wavefront slot still busy");
-        return UMX_ERR_ARG;
-    }
-    int active[4], nact;
-    active_list(flags, active, nact);
-    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
-    if (dbg)
-        for (int tg = 0; tg < 4; ++tg)
-            if (!sl.ta[tg].mask_dbg)
-                if (int rc = dalloc(&sl.ta[tg].mask_dbg, (size_t)T * NOUT))
-                    return rc;
-    last_flags = flags;
-    // the slot's buffers are free once the back stage of the segment that used them last has finished
-    if (sl.used)
-        UMX_HIP_CHECK(hipStreamWaitEvent(sl.stream, sl.back_done, 0));
-    if (int rc = stage_front(sl, sl.stream, audio_dev, n, active, nact))
-        return rc;
-    UMX_HIP_CHECK(hipEventRecord(sl.front_done, sl.stream));
-    for (int s = 0; s < 4; ++s)
-        sl.job_out[s] = out[s];
-    sl.job_n = n;
-    sl.job_flags = flags;
-    sl.job_stage = 0;
-    sl.used = true;
-    cur = si;
-    ++nseg;
-    return wf_launch(true);
-}
-
-// ---------------------------------------------------------------- one segment
+// ---------------------------------------------------------------- one segment (of every track lane)
 int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags)
 {
-    if (!audio_dev || n < 1 || n > N)
+    if (!audio_dev)
     {
         set_error("infer_segment: need 1 <= n <= segment_samples and non-null audio");
         return UMX_ERR_ARG;
     }
-    for (int s = 0; s < 4; ++s)
-        if (!out[s])
+    return infer_batch(1, &audio_dev, &n, out, flags);
+}
+
+int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n, float *const *out, unsigned flags)
+{
+    if (nb < 1 || nb > B || !audio_dev || !n || !out)
+    {
+        set_error("infer: need 1 <= n_tracks <= the context's track count and non-null argument arrays");
+        return UMX_ERR_ARG;
+    }
+    unsigned lane_mask = 0;
+    for (int ln = 0; ln < nb; ++ln)
+    {
+        if (!audio_dev[ln]) // idle lane: its stream state stays as it is
+            continue;
+        if (n[ln] < 1 || n[ln] > N)
         {
-            set_error("infer_segment: null output pointer");
+            set_error("infer_segment: need 1 <= n <= segment_samples and non-null audio");
             return UMX_ERR_ARG;
         }
+        for (int s = 0; s < 4; ++s)
+            if (!out[4 * ln + s])
+            {
+                set_error("infer_segment: null output pointer");
+                return UMX_ERR_ARG;
+            }
+        lane_mask |= 1u << ln;
+    }
+    if (!lane_mask)
+    {
+        set_error("infer: no active track lane");
+        return UMX_ERR_ARG;
+    }
     if (ph_next != -1)
     {
         set_error("infer_segment: a phased segment is open (umx_hip_segment_end first)");
         return UMX_ERR_ARG;
     }
     UMX_HIP_CHECK(hipSetDevice(device));
-    if (wavefront && !(flags & UMX_FLAG_LSTM_STEPWISE) && persistent_ok && 8 * S <= lstm_capacity)
-    {
-        last_was_wavefront = true;
-        return wf_enqueue(audio_dev, n, out, flags);
-    }
-    last_was_wavefront = false;
-    if (wavefront) // per-layer path requested while wavefront jobs may be in flight: drain them first
-    {
-        if (int rc = sync_all())
-            return rc;
-    }
-    // "slots" mode: consecutive segments alternate between two slots/streams; a slot is reused two
-    // segments later (stream order protects its buffers).  Everything that touches the streaming LSTM
-    // state is ordered by events: R_l of this segment waits for R_l of the previous one.
+    // Consecutive calls alternate between two slots/streams; a slot is reused two calls later (stream order
+    // protects its buffers).  Everything that touches the streaming LSTM state is ordered by events: R_l of
+    // this segment waits for R_l of the previous one.
     const int si = (int)(nseg & 1);
     Slot &sl = slot[si];
     Slot &prev = slot[si ^ 1];
@@ -1257,31 +1228,36 @@ int umx_hip_ctx::infer_device(const float *audio_dev, int n, float *const out[4]
     active_list(flags, active, nact);
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
     if (dbg)
-        for (int tg = 0; tg < 4; ++tg)
-            if (!sl.ta[tg].mask_dbg)
-                if (int rc = dalloc(&sl.ta[tg].mask_dbg, (size_t)T * NOUT))
-                    return rc;
+        for (int ln = 0; ln < nb; ++ln)
+            for (int tg = 0; tg < 4; ++tg)
+                if (!sl.lane[ln].ta[tg].mask_dbg)
+                    if (int rc = dalloc(&sl.lane[ln].ta[tg].mask_dbg, (size_t)T * NOUT))
+                        return rc;
     last_flags = flags;
-    if (int rc = stage_front(sl, st, audio_dev, n, active, nact))
+    if (int rc = stage_front(sl, st, nb, audio_dev, n, active, nact))
         return rc;
+    // two LSTM grids at once only where both fit (the single-track kernel); otherwise wait for the previous
+    // segment's last layer
+    const bool two_grids = !lstm_batched && 2 * 8 * S <= lstm_capacity;
     for (int layer = 0; layer < 3; ++layer)
     {
         if (layer > 0)
         {
             UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
             if (nact > 0)
-                launch_gemm(sl, st, G_IH, layer, active, nact, false);
+                for (int ln = 0; ln < nb; ++ln)
+                    if (audio_dev[ln])
+                        launch_gemm(sl.lane[ln], st, G_IH, layer, active, nact, false);
         }
-        if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3); if two
-                       // LSTM grids cannot be co-resident, wait for its last layer instead
-            UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[2 * 8 * S <= lstm_capacity ? layer : 2], 0));
+        if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3)
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[two_grids ? layer : 2], 0));
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
         if (nact > 0)
-            if (int rc = run_lstm_layer(sl, layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE))
+            if (int rc = run_lstm_layer(sl, layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE, lane_mask))
                 return rc;
         UMX_HIP_CHECK(hipEventRecord(sl.rec_done[layer], st));
     }
-    if (int rc = stage_back(sl, st, out, n, flags, active, nact))
+    if (int rc = stage_back(sl, st, nb, audio_dev, out, n, flags, active, nact))
         return rc;
     sl.used = true;
     cur = si;
@@ -1351,8 +1327,8 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     const bool timing = getenv("UMX_TRACK_TIMING") != nullptr;
     const auto tt0 = std::chrono::steady_clock::now();
     // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
-    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * 4 * 12 * Hl));
-    slot[0].used = slot[1].used = slot[2].used = false;
+    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats())); // track lane 0
+    slot[0].used = slot[1].used = false;
     UMX_HIP_CHECK(hipMemset(trk_in, 0, sizeof(float) * 2 * (size_t)L2));
     for (int t = 0; t < 4; ++t)
         UMX_HIP_CHECK(hipMemset(trk_out[t], 0, sizeof(float) * 2 * (size_t)L2));
@@ -1384,11 +1360,8 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     for (long long off = 0; off < L2; off += stride, ++iseg)
     {
         const int offset = (int)off, n = std::min(N, L2 - offset); // umx.cpp:214-217
-        const bool wf = wavefront;
-        wavefront = false; // the track driver uses the two-slot pipeline
         const int si = (int)(nseg & 1);
         const int rc = infer_device(trk_in + 2 * (size_t)offset, n, trk_seg[si], flags);
-        wavefront = wf;
         if (rc)
         {
             cleanup();
@@ -1473,9 +1446,9 @@ int umx_hip_ctx::phase_begin(const float *audio_host, int n, unsigned flags)
     int active[4], nact;
     active_list(flags, active, nact);
     last_flags = flags;
-    last_was_wavefront = false;
     UMX_HIP_CHECK(hipMemcpyAsync(audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, sl.stream));
-    if (int rc = stage_front(sl, sl.stream, audio_in, n, active, nact))
+    const float *ain = audio_in;
+    if (int rc = stage_front(sl, sl.stream, 1, &ain, &n, active, nact))
         return rc;
     ph_next = 0;
     ph_n = n;
@@ -1499,11 +1472,11 @@ int umx_hip_ctx::phase_layer(int layer)
     {
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
         if (nact > 0)
-            launch_gemm(sl, st, G_IH, layer, active, nact, false);
+            launch_gemm(sl.lane[0], st, G_IH, layer, active, nact, false);
     }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
     if (nact > 0)
-        if (int rc = run_lstm_layer(sl, layer, active, nact, ph_flags & UMX_FLAG_LSTM_STEPWISE))
+        if (int rc = run_lstm_layer(sl, layer, active, nact, ph_flags & UMX_FLAG_LSTM_STEPWISE, 1u))
             return rc;
     UMX_HIP_CHECK(hipEventRecord(sl.rec_done[layer], st));
     ph_next = layer + 1;
@@ -1522,14 +1495,15 @@ int umx_hip_ctx::phase_end(float *const out_host[4])
     int active[4], nact;
     active_list(ph_flags, active, nact);
     ph_next = -1;
-    if (int rc = stage_back(sl, sl.stream, out_dev, ph_n, ph_flags, active, nact))
+    const float *ain = audio_in;
+    if (int rc = stage_back(sl, sl.stream, 1, &ain, out_dev, &ph_n, ph_flags, active, nact))
         return rc;
     cur = 0;
     if (int rc = umx_hip_sync(this))
         return rc;
     for (int s = 0; s < 4; ++s)
         UMX_HIP_CHECK(hipMemcpy(out_host[s], out_dev[s], sizeof(float) * 2 * (size_t)ph_n, hipMemcpyDeviceToHost));
-    slot[0].used = slot[1].used = slot[2].used = false; // drained: nothing for the next segment to wait for
+    slot[0].used = slot[1].used = false; // drained: nothing for the next segment to wait for
     return UMX_OK;
 }
 
@@ -1565,8 +1539,6 @@ __global__ __launch_bounds__(256) void lds_guard_kernel(unsigned *errs, int roun
 extern "C"
 {
 
-int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
-                      const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                    const umx_tensor_view *tensors, int n_tensors)
 {
@@ -1577,6 +1549,9 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
     if (const char *e = getenv("UMX_GEMM"))
         if (std::string(e) == "f32")
             cf |= UMX_CREATE_GEMM_F32;
+    if (const char *e = getenv("UMX_LSTM"))
+        if (std::string(e) == "batched")
+            cf |= UMX_CREATE_LSTM_BATCHED;
     return umx_hip_create_ex(out, device, hidden_size, segment_samples, tensors, n_tensors, cf);
 }
 
@@ -1585,6 +1560,12 @@ size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx) { return ctx ? ctx->weight_b
 int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags)
 {
+    return umx_hip_create_tracks(out, device, hidden_size, segment_samples, tensors, n_tensors, create_flags, 1);
+}
+
+int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
+                          const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks)
+{
     if (!out || !tensors)
     {
         g_create_error = "umx_hip_create: null argument";
@@ -1592,7 +1573,7 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
     }
     *out = nullptr;
     umx_hip_ctx *c = new umx_hip_ctx;
-    int rc = c->init(device, hidden_size, segment_samples, tensors, n_tensors, create_flags);
+    int rc = c->init(device, hidden_size, segment_samples, tensors, n_tensors, create_flags, n_tracks);
     if (rc != UMX_OK)
     {
         g_create_error = c->err;
@@ -1603,6 +1584,9 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
     return UMX_OK;
 }
 
+int umx_hip_n_tracks(const umx_hip_ctx *ctx) { return ctx ? ctx->B : 0; }
+int umx_hip_lstm_is_batched(const umx_hip_ctx *ctx) { return ctx && ctx->lstm_batched ? 1 : 0; }
+
 void umx_hip_destroy(umx_hip_ctx *ctx)
 {
     if (!ctx)
@@ -1611,22 +1595,14 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
     (void)hipDeviceSynchronize();
     for (void *p : ctx->allocs)
         (void)hipFree(p);
-    for (hipStream_t q : {ctx->main_stream, ctx->back_stream})
-        if (q)
-            (void)hipStreamDestroy(q);
-    for (int i = 0; i < 3; ++i)
-        if (ctx->lstm_ev[i])
-            (void)hipEventDestroy(ctx->lstm_ev[i]);
     for (hipEvent_t e : ctx->trk_acc_ev)
         if (e)
             (void)hipEventDestroy(e);
-    for (int si = 0; si < 3; ++si)
+    if (ctx->order_ev)
+        (void)hipEventDestroy(ctx->order_ev);
+    for (int si = 0; si < 2; ++si)
     {
         Slot &sl = ctx->slot[si];
-        if (sl.front_done)
-            (void)hipEventDestroy(sl.front_done);
-        if (sl.back_done)
-            (void)hipEventDestroy(sl.back_done);
         for (int i = 0; i <= ST_COUNT; ++i)
             if (sl.ev[i])
                 (void)hipEventDestroy(sl.ev[i]);
@@ -1641,31 +1617,36 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
 
 const char *umx_hip_last_error(const umx_hip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-size_t umx_hip_stream_floats(const umx_hip_ctx *ctx) { return ctx ? (size_t)4 * 12 * ctx->Hl : 0; }
+size_t umx_hip_stream_floats(const umx_hip_ctx *ctx) { return ctx ? ctx->state_floats() : 0; }
 
-int umx_hip_stream_reset(umx_hip_ctx *ctx)
+// track < 0: every lane
+int umx_hip_track_stream_reset(umx_hip_ctx *ctx, int track)
 {
-    if (!ctx)
+    if (!ctx || track >= ctx->B)
         return UMX_ERR_ARG;
     if (int rc = ctx->sync_all())
         return rc;
-    hipError_t e = hipMemset(ctx->state, 0, sizeof(float) * 4 * 12 * ctx->Hl);
+    const size_t per = ctx->state_floats();
+    hipError_t e = track < 0 ? hipMemset(ctx->state, 0, sizeof(float) * per * ctx->B)
+                             : hipMemset(ctx->state + per * track, 0, sizeof(float) * per);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
-    ctx->slot[0].used = ctx->slot[1].used = ctx->slot[2].used = false; // a new track: no cross-segment dependency to wait for
+    ctx->slot[0].used = ctx->slot[1].used = false; // nothing in flight: no cross-segment dependency to wait for
     return UMX_OK;
 }
+int umx_hip_stream_reset(umx_hip_ctx *ctx) { return umx_hip_track_stream_reset(ctx, 0); }
 
-int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst)
+int umx_hip_track_stream_get(umx_hip_ctx *ctx, int track, float *host_dst)
 {
-    if (!ctx || !host_dst)
+    if (!ctx || !host_dst || track < 0 || track >= ctx->B)
         return UMX_ERR_ARG;
     if (int rc = ctx->sync_all())
         return rc;
-    hipError_t e = hipMemcpy(host_dst, ctx->state, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyDeviceToHost);
+    const size_t per = ctx->state_floats();
+    hipError_t e = hipMemcpy(host_dst, ctx->state + per * track, sizeof(float) * per, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
@@ -1673,26 +1654,29 @@ int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst)
     }
     return UMX_OK;
 }
+int umx_hip_stream_get(umx_hip_ctx *ctx, float *host_dst) { return umx_hip_track_stream_get(ctx, 0, host_dst); }
 
-int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src)
+int umx_hip_track_stream_set(umx_hip_ctx *ctx, int track, const float *host_src)
 {
-    if (!ctx || !host_src)
+    if (!ctx || !host_src || track < 0 || track >= ctx->B)
         return UMX_ERR_ARG;
     if (int rc = ctx->sync_all())
         return rc;
-    hipError_t e = hipMemcpy(ctx->state, host_src, sizeof(float) * 4 * 12 * ctx->Hl, hipMemcpyHostToDevice);
+    const size_t per = ctx->state_floats();
+    hipError_t e = hipMemcpy(ctx->state + per * track, host_src, sizeof(float) * per, hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
-    ctx->slot[0].used = ctx->slot[1].used = ctx->slot[2].used = false;
+    ctx->slot[0].used = ctx->slot[1].used = false;
     return UMX_OK;
 }
+int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src) { return umx_hip_track_stream_set(ctx, 0, host_src); }
 
 size_t umx_hip_stream_layer_floats(const umx_hip_ctx *ctx) { return ctx ? (size_t)4 * 4 * ctx->Hl : 0; }
 
-// one layer's (h, c) of all chains: [target][dir][h|c][Hl]
+// one layer's (h, c) of all chains of track lane 0: [target][dir][h|c][Hl]
 static int stream_layer_copy(umx_hip_ctx *ctx, int layer, float *host, bool to_host)
 {
     if (!ctx || !host || layer < 0 || layer > 2)
@@ -1776,15 +1760,63 @@ int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n
     return ctx->infer_device(audio_dev, n, out_dev, flags);
 }
 
+int umx_hip_infer_batch_device(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_dev, const int *n,
+                               float *const *out_dev, unsigned flags)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    return ctx->infer_batch(n_tracks, audio_dev, n, out_dev, flags);
+}
+
+// Ordering against the caller's own HIP streams (the engine alternates between two internal streams)
+int umx_hip_order_after(umx_hip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    hipError_t e = hipSuccess;
+    if (!ctx->order_ev)
+        e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventRecord(ctx->order_ev, (hipStream_t)hip_stream);
+    for (int si = 0; si < 2 && e == hipSuccess; ++si)
+        e = hipStreamWaitEvent(ctx->slot[si].stream, ctx->order_ev, 0);
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    return UMX_OK;
+}
+int umx_hip_order_before(umx_hip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    hipError_t e = hipSuccess;
+    if (!ctx->order_ev)
+        e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming);
+    for (int si = 0; si < 2 && e == hipSuccess; ++si)
+    {
+        e = hipEventRecord(ctx->order_ev, ctx->slot[si].stream);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent((hipStream_t)hip_stream, ctx->order_ev, 0);
+    }
+    if (e != hipSuccess)
+    {
+        ctx->set_error(hipGetErrorString(e));
+        return UMX_ERR_HIP;
+    }
+    return UMX_OK;
+}
+
 int umx_hip_sync(umx_hip_ctx *ctx)
 {
     if (!ctx)
         return UMX_ERR_ARG;
     if (int rc = ctx->sync_all())
         return rc;
-    for (int si = 0; si < ctx->nslots + 1; ++si)
+    for (int si = 0; si < ctx->nslots; ++si)
     {
-        unsigned *dev_status = si < ctx->nslots ? ctx->slot[si].status : ctx->wf_status;
+        unsigned *dev_status = ctx->slot[si].status;
         if (!dev_status)
             continue;
         unsigned st = 0;
@@ -1796,10 +1828,15 @@ int umx_hip_sync(umx_hip_ctx *ctx)
         }
         if (st != 0)
         {
-            ctx->set_error(st == 0x80000000u
-                               ? std::string("persistent LSTM kernel: grid barrier timed out (grid not co-resident)")
-                               : "persistent LSTM kernel timed out waiting for a hidden-state granule (code " +
-                                     std::to_string(st) + ")");
+            // the aborted launch left a mix of updated and stale chains behind: the stream state of every track
+            // lane is reset, and the caller is told so (continuing a track after this needs umx_hip_*stream_set)
+            (void)hipMemset(ctx->state, 0, sizeof(float) * ctx->state_floats() * ctx->B);
+            ctx->slot[0].used = ctx->slot[1].used = false;
+            ctx->set_error((st == 0x80000000u
+                                ? std::string("persistent LSTM kernel: grid barrier timed out (grid not co-resident)")
+                                : "persistent LSTM kernel timed out waiting for a hidden-state granule (code " +
+                                      std::to_string(st) + ")") +
+                           "; the streaming LSTM state was reset to zero, later segments run the per-step driver");
             (void)hipMemset(dev_status, 0, sizeof(unsigned));
             ctx->persistent_ok = false;
             return UMX_ERR_TIMEOUT;
@@ -1808,42 +1845,81 @@ int umx_hip_sync(umx_hip_ctx *ctx)
     return UMX_OK;
 }
 
-int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4], unsigned flags)
+// Host-pointer forms.  H2D, kernels and D2H are queued on the stream of the pipeline slot the segment runs in, so
+// with PINNED host buffers consecutive _async calls overlap one segment's transfers with the other's kernels.
+int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *n,
+                              float *const *out_host, unsigned flags)
 {
-    if (!ctx || !audio_host || !out_host || n < 1 || n > ctx->N)
+    if (!ctx || !audio_host || !n || !out_host || n_tracks < 1 || n_tracks > ctx->B)
     {
         if (ctx)
-            ctx->set_error("infer_segment: bad arguments");
+            ctx->set_error("infer: bad arguments");
         return UMX_ERR_ARG;
     }
-    // the staging buffers are shared, so the host-pointer form is strictly one segment at a time
-    if (int rc = ctx->sync_all())
+    const int si = (int)(ctx->nseg & 1);
+    if (int rc = ctx->ensure_staging())
         return rc;
-    hipStream_t st = ctx->slot[ctx->wavefront ? ctx->nseg % 3 : ctx->nseg & 1].stream;
-    hipError_t e = hipMemcpyAsync(ctx->audio_in, audio_host, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess)
+    hipStream_t st = ctx->slot[si].stream;
+    const float *ain[LSTMB_MAX_TRACKS] = {};
+    for (int ln = 0; ln < n_tracks; ++ln)
     {
-        ctx->set_error(hipGetErrorString(e));
-        return UMX_ERR_HIP;
-    }
-    int rc = ctx->infer_device(ctx->audio_in, n, ctx->out_dev, flags);
-    if (rc)
-        return rc;
-    // results are complete only after the pipeline has drained (wavefront mode finishes the segment's
-    // layers 1 and 2 and its back stage during the flush)
-    rc = umx_hip_sync(ctx);
-    if (rc)
-        return rc;
-    for (int s = 0; s < 4; ++s)
-    {
-        e = hipMemcpy(out_host[s], ctx->out_dev[s], sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost);
+        if (!audio_host[ln])
+            continue;
+        if (n[ln] < 1 || n[ln] > ctx->N)
+        {
+            ctx->set_error("infer_segment: need 1 <= n <= segment_samples");
+            return UMX_ERR_ARG;
+        }
+        float *dst = ctx->stage_in[si] + (size_t)2 * ctx->N * ln;
+        hipError_t e = hipMemcpyAsync(dst, audio_host[ln], sizeof(float) * 2 * (size_t)n[ln], hipMemcpyHostToDevice, st);
         if (e != hipSuccess)
         {
             ctx->set_error(hipGetErrorString(e));
             return UMX_ERR_HIP;
         }
+        ain[ln] = dst;
     }
+    if (int rc = ctx->infer_batch(n_tracks, ain, n, ctx->stage_out[si], flags))
+        return rc;
+    for (int ln = 0; ln < n_tracks; ++ln)
+        if (ain[ln])
+            for (int s = 0; s < 4; ++s)
+            {
+                hipError_t e = hipMemcpyAsync(out_host[4 * ln + s], ctx->stage_out[si][4 * ln + s], sizeof(float) * 2 * (size_t)n[ln],
+                                              hipMemcpyDeviceToHost, st);
+                if (e != hipSuccess)
+                {
+                    ctx->set_error(hipGetErrorString(e));
+                    return UMX_ERR_HIP;
+                }
+            }
     return UMX_OK;
+}
+
+int umx_hip_infer_batch(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *n, float *const *out_host,
+                        unsigned flags)
+{
+    if (int rc = umx_hip_infer_batch_async(ctx, n_tracks, audio_host, n, out_host, flags))
+        return rc;
+    return umx_hip_sync(ctx);
+}
+
+int umx_hip_infer_segment_async(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4], unsigned flags)
+{
+    if (!ctx || !audio_host || !out_host)
+    {
+        if (ctx)
+            ctx->set_error("infer_segment: bad arguments");
+        return UMX_ERR_ARG;
+    }
+    return umx_hip_infer_batch_async(ctx, 1, &audio_host, &n, out_host, flags);
+}
+
+int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4], unsigned flags)
+{
+    if (int rc = umx_hip_infer_segment_async(ctx, audio_host, n, out_host, flags))
+        return rc;
+    return umx_hip_sync(ctx); // umx_inference returns its outputs: synchronous
 }
 
 void *umx_hip_stream_handle(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->slot[ctx->cur].stream : nullptr; }
@@ -1857,7 +1933,18 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
         return -1;
     std::string w = what;
     const int T = ctx->T, H = ctx->H;
-    int which = ctx->cur;
+    int which = ctx->cur, lane = 0;
+    {
+        const size_t hash = w.find('#'); // "name#k": track lane k (default 0)
+        if (hash != std::string::npos)
+        {
+            lane = atoi(w.c_str() + hash + 1);
+            const size_t at = w.find('@', hash);
+            w = w.substr(0, hash) + (at == std::string::npos ? "" : w.substr(at));
+            if (lane < 0 || lane >= ctx->B)
+                return -1;
+        }
+    }
     if (w.size() > 2 && w[w.size() - 2] == '@') // "name@s": pipeline slot s instead of the most recent one
     {
         which = w.back() - '0';
@@ -1865,7 +1952,7 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
         if (which < 0 || which >= ctx->nslots)
             return -1;
     }
-    const Slot &sl = ctx->slot[which];
+    const Lane &sl = ctx->slot[which].lane[lane];
     const void *src = nullptr;
     size_t nfl = 0, src_ld = 0, rows = 0, cols = 0; // strided copy when src_ld != cols
     if (w == "spec") { src = sl.spec; nfl = (size_t)2 * 2 * T * NBINS; }
@@ -1876,6 +1963,7 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
     else if (w == "lstm_l0") { src = sl.ta[target].la; nfl = (size_t)T * H; }
     else if (w == "lstm_l1") { src = sl.ta[target].lb; nfl = (size_t)T * H; }
     else if (w == "proj") { src = sl.ta[target].P; nfl = (size_t)T * 4 * H; }
+    else if (w == "fc2") { src = sl.ta[target].a2; nfl = (size_t)T * H; }
     else if (w == "mask") { src = sl.ta[target].mask_dbg; nfl = (size_t)T * NOUT; }
     else if (w == "target_mag") { src = sl.ta[target].mag; nfl = (size_t)2 * T * NBINS; }
     else if (w == "y") { src = sl.y + (size_t)target * 2 * T * NBINS; nfl = (size_t)2 * 2 * T * NBINS; }
@@ -1944,7 +2032,7 @@ int umx_hip_lstm_mode(umx_hip_ctx *ctx)
     if (!ctx || !ctx->slot[ctx->cur].last_persistent)
         return 0;
     unsigned st[2] = {0, 0};
-    const unsigned *src = ctx->last_was_wavefront ? ctx->wf_status : ctx->slot[ctx->cur].status;
+    const unsigned *src = ctx->slot[ctx->cur].status;
     if (ctx->sync_all() != UMX_OK || hipMemcpy(st, src, sizeof st, hipMemcpyDeviceToHost) != hipSuccess)
         return -1;
     return st[1] ? 2 : 1;
@@ -1955,7 +2043,7 @@ int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48)
     if (!ctx || !out48)
         return UMX_ERR_ARG;
     if (ctx->sync_all() != UMX_OK ||
-        hipMemcpy(out48, ctx->slot[ctx->last_was_wavefront ? 0 : ctx->cur].lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
+        hipMemcpy(out48, ctx->slot[ctx->cur].lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
         return UMX_ERR_HIP;
     return UMX_OK;
 }

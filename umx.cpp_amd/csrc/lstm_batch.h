@@ -1,0 +1,491 @@
+// lstm_batch.h -- the streaming LSTM recurrence (lstm.cpp:101-179) for a BATCH of up to 16 independent tracks
+// (SURVEY 8f-4).  Same chains, same sharding and the same granule hand-off as lstm_kernels.h, but the per-step
+// matrix-vector product W_hh h of one track becomes the matrix-matrix product
+//         gates[64 gate columns of this workgroup][16 tracks] = W_hh-slice [64 x Hl] . H [Hl x 16 tracks]
+// which is what the matrix cores are for: v_mfma_f32_16x16x32_bf16 with fp32 accumulation and the three-term bf16
+// split of gemm_bf16x3.h, so the arithmetic stays fp32-class.  One serial step -- hand-off, barrier,
+// gates -- now advances every track of the batch, which is the only way to lift a latency-bound recurrence.
+//
+// Work split (unchanged): workgroup (chain, slice) owns 16 hidden units = 64 gate columns (column = 4*unit + gate,
+// gates i|f|g|o, lstm.cpp:143-152); 512 threads = 8 waves; wave w owns the k-range [w*Hl/8, (w+1)*Hl/8) of the
+// contraction.
+//   A operand = W_hh: M = gate column (4 tiles of 16), kept in VGPRs for the whole launch
+//       general form (fp32 or dequantised weights): three bf16 planes, six products a1b1+a1b2+a2b1+a2b2+a1b3+a3b1
+//       u8-resident W_hh (the ggml file's own storage, the default): q - 128 is an integer in [-128, 127] and therefore
+//       EXACT in bf16: one plane, three products (q-128).(h1+h2+h3), and the affine map of model.cpp:610-616 is
+//       applied to the sum:  W_hh h = scale * sum_k (q_k - 128) h_k + (offset + 128 scale) * sum_k h_k.  The second
+//       sum comes out of a fifth M tile whose A operand is all ones.  (The reference rounds q*scale+offset to fp32
+//       per weight first; the two differ by that rounding, ~1e-7 of the dot product, the size of one fp32 rounding
+//       of the sum itself.)
+//   B operand = h_{t-1}: N = track (lane & 15), K = hidden unit.  The producer publishes h ALREADY SPLIT: one
+//       8-byte granule per (unit, track) = {tag:16, h1:16, h2:16, h3:16} (h = h1 + h2 + h3 exactly, bf16 terms) --
+//       the same 8 bytes as lstm_kernels.h's {tag, fp32}, still one naturally aligned store that is its own flag,
+//       and the consumer feeds the matrix core without converting anything.  A lane fetches its B fragment (8 units of
+//       one track) with four 16-byte loads per K step, each of them contiguous across the wave (lstmb_granule_index).
+//   C = the 4 gates of unit 4*tile + (lane>>4) for track lane&15 sit in ONE lane (rows of the 16x16 result are
+//       4*(lane>>4)+reg): no cross-lane traffic in the gate phase.  The eight k-range partials meet through LDS
+//       (float4 per lane, conflict-free), summed in a fixed tree: results never depend on the batch size or on
+//       which lanes of the batch are active (an absent track is a zero column of B).
+// Everything else -- census / intra-XCD vs sc1 protocol, bounded spins, bulk W_ih-row ring through global_load_lds,
+// the in-kernel profiler -- follows lstm_kernels.h.  A launch covers the steps [t_begin, t_end) and starts from /
+// leaves behind the fp32 (h, c) stream state, so the same kernel run one step per launch is the bit-identical
+// fallback (and cross-check) that needs no co-residency.
+#pragma once
+#include "gemm_bf16x3.h"
+#include "lstm_kernels.h"
+
+namespace umx
+{
+
+constexpr int LSTMB_MAX_TRACKS = 16;
+// x64 shader cycles a wave sleeps before its first poll of a step.  A wave that also runs the gate phase has just
+// published and needs one hand-off latency; the other waves come straight from the barrier and have the whole gate
+// phase in front of them -- polling through it would only load the L2 (every failed attempt is 8 x 16 B per lane)
+// and take issue slots from the gate wave sharing their SIMD.
+#ifndef LSTMB_DELAY_GATE
+#define LSTMB_DELAY_GATE 0
+#endif
+#ifndef LSTMB_DELAY_IDLE
+#define LSTMB_DELAY_IDLE 24
+#endif
+#ifndef LSTMB_DEFER_OUT
+#define LSTMB_DEFER_OUT 1
+#endif
+#ifndef LSTMB_PROF_WAVE
+#define LSTMB_PROF_WAVE 4 // the second wave the in-kernel profiler reports (beside wave 0): 4..7 = a wave without gate work
+#endif
+#ifndef LSTMB_RETRY_SLEEP
+#define LSTMB_RETRY_SLEEP 1 // x64 cycles between failed polls
+#endif
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct LstmBArgs
+{
+    const float *W;          // this layer: [chains][S][Hl][64] fp32 ...
+    const unsigned char *Wq; // ... or (W == nullptr) the ggml file's u8 in the same layout
+    float wsc[8], wof[8];    // per weight chain: scale, offset (model.cpp:610-616)
+    const float *bhh;        // [chains][S][64]
+    const float *P[4];       // track lane n of target i: P[i] + n * p_stride
+    float *out[4];           // out[i] + n * out_stride + t*ldo + col0 + dir*Hl + unit
+    float *state;            // lane n: state + n * state_stride, then [4 targets][3 layers][2 dirs][2 (h,c)][Hl]
+    size_t p_stride, out_stride, state_stride;
+    unsigned *sync;          // [0..7] census, [8] arrivals, [LSTM_SYNC_HEADER_WORDS..] granules u64 [2][8][Hl/8][16][8]
+    unsigned *status;
+    unsigned long long *prof;
+    int Hl, S, T, ldp, ldo, col0, layer, nchains;
+    int tmap[4];
+    int force_safe;
+    unsigned tag_epoch; // 4 bits used: a granule's tag is (epoch << 12) | (step + 1)
+    unsigned lane_mask; // bit n = track lane n takes part in this launch
+    int nbp;            // lanes the LDS arrays are sized for: power of two >= highest active lane + 1
+    int bulk;           // W_ih-row ring: rows per bulk fetch (ring = 2 * bulk rows)
+    int t_begin, t_end; // steps of this launch
+    int census;         // 1: take the census (t_end - t_begin > 1: needs the grid co-resident); 0: static roles
+};
+
+__host__ __device__ inline size_t lstmb_granule_words(int Hl) { return (size_t)2 * 8 * Hl * 16 * 2; } // 32-bit words
+// u64 index of the granule of (step parity slot, chain, hidden unit k, track n).  Within a K step (32 units) the order
+// is [pair of units i = (k%8)/2][8-unit group q = (k%32)/8][track][k%2]: the consumer's i-th 16-byte load is then
+// CONTIGUOUS across the wave (lane = q*16 + n), one L2 request per 128 B instead of one per 16 B, and the tracks of a
+// launch are packed (nbp), so small batches do not spread over sixteen times the lines.
+__host__ __device__ inline size_t lstmb_granule_index(int slot, int chain, int k, int n, int Hl, int nbp)
+{
+    return (((((size_t)(slot * 8 + chain) * (Hl / 32) + (k >> 5)) * 4 + ((k & 7) >> 1)) * 4 + ((k & 31) >> 3)) * nbp + n) * 2 + (k & 1);
+}
+__host__ __device__ inline size_t lstmb_lds_bytes(int nbp, int bulk)
+{
+    return (size_t)2 * 8 * 16 * nbp * 16 /* part */ + (size_t)2 * bulk * nbp * 256 /* ring */;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
+
+// sum of the NDW k-range partials in a fixed tree
+template <int NDW> __device__ __forceinline__ float tree_sum(const float (&p)[8])
+{
+    if (NDW == 8)
+        return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    if (NDW == 4)
+        return (p[0] + p[1]) + (p[2] + p[3]);
+    if (NDW == 2)
+        return p[0] + p[1];
+    return p[0];
+}
+
+template <int HL, bool WQ, bool FAST, bool PRECISE>
+__device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int slice, unsigned char *smem, int *abort_flag)
+{
+    constexpr int NKS = HL / 32;                 // K steps (32 hidden units each) of the whole contraction
+    constexpr int KSW = NKS >= 8 ? NKS / 8 : 1;  // K steps per dot wave
+    constexpr int NDW = NKS >= 8 ? 8 : NKS;      // waves that multiply (all 8 for Hl >= 256)
+    constexpr int NPL = WQ ? 1 : 3;              // bf16 planes of W_hh held in registers
+    const int target = a.tmap[chain >> 1], dir = chain & 1, wchain = target * 2 + dir;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, q = l >> 4;
+    const int nbp = a.nbp, bulk = a.bulk, ring_mask = 2 * bulk - 1, T = a.T, S = a.S;
+    const unsigned lane_mask = a.lane_mask;
+    const bool lane_on = (lane_mask >> n) & 1u;
+    const bool dot_wave = w < NDW, gate_wave = w < 4; // gate wave w finishes M tile w (units 4w .. 4w+3 of the slice)
+
+    float4 *part = reinterpret_cast<float4 *>(smem);                                   // [2][8 waves][4 tiles][4 q][nbp]
+    float *ring = reinterpret_cast<float *>(smem + (size_t)2 * 8 * 16 * nbp * 16);     // [2*bulk rows][nbp][64]
+
+    // ---- W_hh fragments: lane (i = l & 15, q) of tile mt holds gate column 16 mt + i, units k = 32 ks' + 8 q + j
+    bf16x8 Wf[4][KSW][NPL];
+    if (dot_wave)
+    {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks)
+            {
+                float wv[8];
+                const size_t base = (((size_t)wchain * S + slice) * HL + (size_t)(w * KSW + ks) * 32 + 8 * q) * 64 + 16 * mt + n;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    wv[j] = WQ ? (float)a.Wq[base + (size_t)j * 64] - 128.0f : whh_at(a.W, a.Wq, a.wsc[wchain], a.wof[wchain], base + (size_t)j * 64);
+                uint4 p1, p2, p3;
+                split3(wv, p1, p2, p3); // WQ: wv is an integer in [-128, 127] -> p1 exact, p2 = p3 = 0
+                Wf[mt][ks][0] = as_bf16x8(p1);
+                if (!WQ)
+                {
+                    Wf[mt][ks][NPL > 1 ? 1 : 0] = as_bf16x8(p2);
+                    Wf[mt][ks][NPL > 2 ? 2 : 0] = as_bf16x8(p3);
+                }
+            }
+    }
+    const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
+    const float wsc = a.wsc[wchain], wof2 = a.wof[wchain] + 128.0f * a.wsc[wchain]; // WQ: W h = wsc * A + wof2 * sum(h)
+
+    // ---- per-(unit, track) cell state of the gate lanes, b_hh of the unit's four gates
+    const int unit = slice * 16 + 4 * (w & 3) + q;
+    const size_t st_h = (size_t)n * a.state_stride + state_off(target, a.layer, dir, 0, HL);
+    const size_t st_c = (size_t)n * a.state_stride + state_off(target, a.layer, dir, 1, HL);
+    float c = 0.f, hlast = 0.f;
+    float4 bh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gate_wave)
+    {
+        bh = *reinterpret_cast<const float4 *>(a.bhh + ((size_t)wchain * S + slice) * 64 + 4 * (4 * w + q));
+        if (lane_on)
+        {
+            c = a.state[st_c + unit];
+            hlast = a.state[st_h + unit];
+        }
+    }
+    // ---- h_{t_begin - 1} from the fp32 stream state, split like a published granule
+    bf16x8 hf[KSW][3];
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks)
+    {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            hv[j] = (dot_wave && lane_on) ? a.state[st_h + (w * KSW + ks) * 32 + 8 * q + j] : 0.f;
+        uint4 p1, p2, p3;
+        split3(hv, p1, p2, p3);
+        hf[ks][0] = as_bf16x8(p1);
+        hf[ks][1] = as_bf16x8(p2);
+        hf[ks][2] = as_bf16x8(p3);
+    }
+
+    gu64 *gran = (gu64 *)(a.sync + LSTM_SYNC_HEADER_WORDS);
+    // the polls are 16-byte L1-bypassing buffer loads (buffer_load_dwordx4 ... sc1): two granules each
+    const __amdgpu_buffer_rsrc_t gran_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.sync + LSTM_SYNC_HEADER_WORDS, 0, (int)(lstmb_granule_words(HL) * 4), 0x00020000);
+    gu32 *status = (gu32 *)a.status;
+    const float *const Pp = a.P[target] + ((size_t)dir * S + slice) * 64 + l;
+    float *const outp = a.out[target] + (size_t)n * a.out_stride + a.col0 + dir * HL + unit;
+    const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo, p_stride = a.p_stride;
+    const unsigned tag_hi = (a.tag_epoch & 15u) << 12;
+    const int t_begin = a.t_begin, t_end = a.t_end;
+
+    // W_ih x + b_ih rows: bulk fetch into the LDS ring (see lstm_kernels.h for why), rows x active lanes dealt to the
+    // dot waves; a wave-instruction moves the 64 columns of one (row, track)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+    const unsigned ring_lds = (unsigned)(size_t)(lds_ptr)ring;
+    auto fetch_rows = [&](int first_row) {
+        const int items = bulk * nbp;
+        for (int i = w; i < items; i += NDW)
+        {
+            const int r = first_row + i / nbp, nn = i % nbp;
+            if (r < t_end && ((lane_mask >> nn) & 1u))
+                __builtin_amdgcn_global_load_lds((glb_ptr)(Pp + (size_t)nn * p_stride + (size_t)(dir == 0 ? r : T - 1 - r) * ldp),
+                                                 (lds_ptr)(size_t)(ring_lds + 256u * (unsigned)((r & ring_mask) * nbp + nn)), 4, 0, 0);
+        }
+    };
+    if (dot_wave)
+    {
+        fetch_rows(t_begin);
+        fetch_rows(t_begin + bulk);
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+    }
+    __syncthreads(); // the first rows are read before the first step's barrier
+    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
+    const int pw_idx = w == 0 ? 0 : 1;
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pc6 = 0, pc7 = 0;
+    unsigned prof_spins = 0;
+
+    for (int step = t_begin; step < t_end; ++step)
+    {
+#if !LSTMB_DEFER_OUT
+        const int t = dir == 0 ? step : T - 1 - step;
+#endif
+        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (prof)
+            c0 = clock64();
+        if (dot_wave)
+        {
+            if (step > t_begin)
+            {
+                // h_{step-1}: granules of slot (step-1)&1 tagged `step`; this lane's 8 units x KSW K steps of track n
+                const unsigned want = tag_hi | (unsigned)step;
+                int goff[KSW]; // byte offset of this lane's first 16 B (units 0,1 of its 8) inside the granule area
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks)
+                    goff[ks] = (int)(lstmb_granule_index((step - 1) & 1, chain, (w * KSW + ks) * 32 + 8 * q, n, HL, nbp) * 8);
+                if (FAST)
+                {
+                    if (gate_wave)
+                        __builtin_amdgcn_s_sleep(LSTMB_DELAY_GATE);
+                    else
+                        __builtin_amdgcn_s_sleep(LSTMB_DELAY_IDLE);
+                }
+                uint4 v[KSW][4];
+                unsigned spins = 0;
+                long long cs = 0;
+                if (prof)
+                    cs = clock64();
+                for (;;)
+                {
+                    bool ok = true;
+                    if (lane_on)
+                    {
+#pragma unroll
+                        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                v[ks][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gran_rs, goff[ks] + i * 64 * nbp, 0, 16)); // sc1
+                        unsigned bad = 0;
+#pragma unroll
+                        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                bad |= (v[ks][i].x ^ want) | (v[ks][i].z ^ want);
+                        ok = (bad & 0xffffu) == 0;
+                    }
+                    if (prof && spins == 0)
+                    {
+                        const long long ce = clock64();
+                        pc6 += (unsigned long long)(cs - c0); // sleep
+                        pc7 += (unsigned long long)(ce - cs); // first round of loads
+                    }
+                    if (__all(ok))
+                        break;
+                    if (++spins > LSTM_SPIN_LIMIT ||
+                        ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                    {
+                        if (l == 0)
+                            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *abort_flag = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(LSTMB_RETRY_SLEEP);
+                }
+                prof_spins = spins;
+                // granule = {lo: tag | h1 << 16, hi: h2 | h3 << 16}; a 16-byte load holds units (2i, 2i+1)
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks)
+                {
+                    uint4 p1, p2, p3;
+                    unsigned *d1 = &p1.x, *d2 = &p2.x, *d3 = &p3.x;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        const uint4 x = lane_on ? v[ks][i] : make_uint4(0u, 0u, 0u, 0u);
+                        d1[i] = (x.x >> 16) | (x.z & 0xffff0000u);
+                        d2[i] = (x.y & 0xffffu) | (x.w << 16);
+                        d3[i] = (x.y >> 16) | (x.w & 0xffff0000u);
+                    }
+                    hf[ks][0] = as_bf16x8(p1);
+                    hf[ks][1] = as_bf16x8(p2);
+                    hf[ks][2] = as_bf16x8(p3);
+                }
+                // every gate wave of this workgroup is past iteration step - 2 (it has crossed the barrier of step - 1),
+                // so ring rows <= step - 2 may be replaced: rows [step-1+bulk, step-1+2 bulk) take the slots of
+                // [step-1-bulk, step-1); they are first read bulk - 1 barriers from now
+                if (step - t_begin > bulk && ((step - t_begin) & (bulk - 1)) == 1)
+                    fetch_rows(step - 1 + bulk);
+            }
+#if LSTMB_DEFER_OUT
+            // the output row of the PREVIOUS step goes out here, behind the polls: vector memory operations complete
+            // in order, and a store queued in front of the poll loads would sit on the hand-off's critical path
+            if (gate_wave && lane_on && step > t_begin)
+                outp[(size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast; // lstm.cpp:163-164,170-171
+#endif
+            if (prof)
+                c1 = clock64();
+            floatx4 acc[4], accH = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#define LSTMB_TERM(PW, PH)                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)            \
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[mt][ks][PW], hf[ks][PH], acc[mt], 0, 0, 0);
+            if (WQ)
+            {
+                // smallest terms first
+                LSTMB_TERM(0, 2)
+                LSTMB_TERM(0, 1)
+                LSTMB_TERM(0, 0)
+#pragma unroll
+                for (int ph = 2; ph >= 0; --ph)
+#pragma unroll
+                    for (int ks = 0; ks < KSW; ++ks)
+                        accH = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, hf[ks][ph], accH, 0, 0, 0);
+            }
+            else
+            {
+                LSTMB_TERM(NPL > 2 ? 2 : 0, 0)
+                LSTMB_TERM(0, 2)
+                LSTMB_TERM(NPL > 1 ? 1 : 0, 1)
+                LSTMB_TERM(NPL > 1 ? 1 : 0, 0)
+                LSTMB_TERM(0, 1)
+                LSTMB_TERM(0, 0)
+            }
+#undef LSTMB_TERM
+            if (n < nbp)
+            {
+                float4 *pw = part + ((size_t)(((step & 1) * 8 + w) * 4) * 4 + q) * nbp + n;
+                // WQ: this k-range's share of W_hh h = wsc * sum (q-128) h + (wof + 128 wsc) * sum h (every row of accH
+                // holds the same sum of h)
+                const float hs = WQ ? wof2 * accH[0] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    pw[(size_t)mt * 4 * nbp] = WQ ? make_float4(wsc * acc[mt][0] + hs, wsc * acc[mt][1] + hs, wsc * acc[mt][2] + hs, wsc * acc[mt][3] + hs)
+                                                  : make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+            }
+        }
+        // W_ih x + b_ih of this lane's unit and track (in the ring since at least one barrier ago)
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gate_wave && n < nbp)
+            p4 = *reinterpret_cast<const float4 *>(ring + ((size_t)((step & ring_mask) * nbp + n)) * 64 + 4 * (4 * w + q));
+        if (prof)
+            c2 = clock64();
+        __syncthreads();
+        if (*abort_flag)
+            return;
+        if (prof)
+            c3 = clock64();
+        if (gate_wave && n < nbp)
+        {
+#if LSTM_GATE_PRIO
+            __builtin_amdgcn_s_setprio(LSTM_GATE_PRIO);
+#endif
+            float px[8], py[8], pz[8], pw_[8];
+#pragma unroll
+            for (int ww = 0; ww < NDW; ++ww)
+            {
+                const float4 v4 = part[((size_t)((((step & 1) * 8 + ww) * 4 + w) * 4) + q) * nbp + n];
+                px[ww] = v4.x;
+                py[ww] = v4.y;
+                pz[ww] = v4.z;
+                pw_[ww] = v4.w;
+            }
+            const float s0 = tree_sum<NDW>(px), s1 = tree_sum<NDW>(py), s2 = tree_sum<NDW>(pz), s3 = tree_sum<NDW>(pw_);
+            // ((W_ih x + b_ih) + W_hh h) + b_hh, lstm.cpp:132-140
+            const float pre_i = (p4.x + s0) + bh.x, pre_f = (p4.y + s1) + bh.y, pre_g = (p4.z + s2) + bh.z, pre_o = (p4.w + s3) + bh.w;
+            float i_t, f_t, g_t, o_t;
+            if (PRECISE)
+            {
+                i_t = sigmoid_ref(pre_i);
+                f_t = sigmoid_ref(pre_f);
+                g_t = tanhf(pre_g);
+                o_t = sigmoid_ref(pre_o);
+            }
+            else
+            {
+                i_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_i));
+                f_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_f));
+                g_t = tanh_hw(pre_g);
+                o_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_o));
+            }
+            const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
+            const float h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
+            if (lane_on)
+            {
+                c = c_t;
+                hlast = h;
+                // publish h split in three bf16 terms, tagged step + 1
+                const unsigned b1 = cvt_pk_bf16(h, 0.f) & 0xffffu;
+                const float r1 = h - __uint_as_float(b1 << 16);
+                const unsigned b2 = cvt_pk_bf16(r1, 0.f) & 0xffffu;
+                const float r2 = r1 - __uint_as_float(b2 << 16);
+                const unsigned b3 = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+                const unsigned long long gv = (unsigned long long)(tag_hi | (unsigned)(step + 1) | (b1 << 16)) |
+                                              ((unsigned long long)(b2 | (b3 << 16)) << 32);
+                granule_store<FAST>(gran + lstmb_granule_index(step & 1, chain, unit, n, HL, nbp), gv);
+#if !LSTMB_DEFER_OUT
+                outp[(size_t)t * ldo] = h; // lstm.cpp:163-164,170-171
+#endif
+            }
+#if LSTM_GATE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+        }
+        if (prof)
+        {
+            const long long c4 = clock64();
+            pc[0] += (unsigned long long)(c1 - c0);
+            pc[1] += (unsigned long long)(c2 - c1);
+            pc[2] += (unsigned long long)(c3 - c2);
+            pc[3] += (unsigned long long)(c4 - c3);
+            pc[4] += 1;
+            pc[5] += prof_spins;
+        }
+    }
+    if (gate_wave && lane_on) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
+    {
+#if LSTMB_DEFER_OUT
+        if (t_end > t_begin)
+            outp[(size_t)(dir == 0 ? t_end - 1 : T - t_end) * ldo] = hlast;
+#endif
+        a.state[st_h + unit] = hlast;
+        a.state[st_c + unit] = c;
+    }
+    if (prof && l == 0)
+    {
+        for (int i = 0; i < 6; ++i)
+            a.prof[(a.layer * 2 + pw_idx) * 8 + i] = (t_begin == 0 ? 0ull : a.prof[(a.layer * 2 + pw_idx) * 8 + i]) + pc[i];
+        a.prof[(a.layer * 2 + pw_idx) * 8 + 6] = pc6;
+        a.prof[(a.layer * 2 + pw_idx) * 8 + 7] = pc7;
+    }
+}
+
+// grid = 8*S workgroups (1-D), plain launch; chunks of more than one step need the grid co-resident (census = 1)
+template <int HL, bool WQ, bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_batch_kernel(LstmBArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstmb_smem[];
+    __shared__ int s_ctl[4]; // chain, slice, fast, abort
+    const int tid = threadIdx.x, S = a.S;
+    if (tid == 0)
+    {
+        if (a.census)
+            lstm_census(a.sync, a.status, S, (int)gridDim.x, a.force_safe, s_ctl);
+        else
+        {
+            s_ctl[0] = (int)(blockIdx.x / S);
+            s_ctl[1] = (int)(blockIdx.x % S);
+            s_ctl[2] = 0;
+            s_ctl[3] = 0;
+        }
+    }
+    __syncthreads();
+    const int chain = s_ctl[0], slice = s_ctl[1];
+    if (s_ctl[3] || chain >= a.nchains)
+        return;
+    if (s_ctl[2])
+        lstmb_body<HL, WQ, true, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3]);
+    else
+        lstmb_body<HL, WQ, false, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3]);
+}
+
+} // namespace umx

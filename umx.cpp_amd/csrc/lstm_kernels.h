@@ -97,6 +97,10 @@ __device__ __forceinline__ float whh_at(const LstmArgs &a, int wchain, size_t id
 {
     return a.W ? a.W[idx] : (float)a.Wq[idx] * a.wsc[wchain] + a.wof[wchain];
 }
+__device__ __forceinline__ float whh_at(const float *W, const unsigned char *Wq, float sc, float of, size_t idx)
+{
+    return W ? W[idx] : (float)Wq[idx] * sc + of;
+}
 __device__ __forceinline__ float4 whh_at4(const LstmArgs &a, int wchain, size_t idx) // idx % 4 == 0
 {
     if (a.W)
@@ -322,6 +326,42 @@ template <bool FAST> __device__ __forceinline__ void granule_store(gu64 *p, unsi
 __device__ __forceinline__ unsigned long long granule_load(gu64 *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // global_load_dwordx2 ... sc1
+}
+
+// Census (thread 0 of every workgroup): register on the XCD this workgroup actually runs on, one bounded grid
+// barrier, then roles: if every XCD received exactly S workgroups, chain = XCD and slice = arrival ticket with the
+// intra-L2 protocol (ctl[2] = 1); otherwise static roles and the placement-independent sc1 protocol.
+// ctl = {chain, slice, fast, abort}
+__device__ __forceinline__ void lstm_census(unsigned *sync, unsigned *status_, int S, int nwg, int force_safe, int *ctl)
+{
+    gu32 *census = (gu32 *)sync;
+    gu32 *arrived = (gu32 *)(sync + 8);
+    gu32 *status = (gu32 *)status_;
+    const unsigned xcc = xcc_id() & 7;
+    const unsigned ticket = __hip_atomic_fetch_add(census + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int abort_ = 0;
+    while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg)
+    {
+        if (++spins > LSTM_SPIN_LIMIT)
+        {
+            __hip_atomic_store(status, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            abort_ = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bool fast = !force_safe && !abort_;
+    for (int x = 0; x < 8; ++x)
+        fast = fast && __hip_atomic_load(census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)S;
+    ctl[0] = fast ? (int)xcc : (int)(blockIdx.x / S);
+    ctl[1] = fast ? (int)ticket : (int)(blockIdx.x % S);
+    ctl[2] = fast;
+    ctl[3] = abort_;
+    if (blockIdx.x == 0)
+        __hip_atomic_store(status + 1, fast ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64, even.
@@ -699,36 +739,7 @@ template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_TH
     __builtin_amdgcn_s_setprio(3);
 #endif
     if (tid == 0)
-    {
-        gu32 *census = (gu32 *)a.sync;
-        gu32 *arrived = (gu32 *)(a.sync + 8);
-        gu32 *status = (gu32 *)a.status;
-        const unsigned xcc = xcc_id() & 7;
-        const unsigned ticket = __hip_atomic_fetch_add(census + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        int abort_ = 0;
-        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nwg)
-        {
-            if (++spins > LSTM_SPIN_LIMIT)
-            {
-                __hip_atomic_store(status, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                abort_ = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        bool fast = !a.force_safe && !abort_;
-        for (int x = 0; x < 8; ++x)
-            fast = fast && __hip_atomic_load(census + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)S;
-        s_ctl[0] = fast ? (int)xcc : (int)(blockIdx.x / S);
-        s_ctl[1] = fast ? (int)ticket : (int)(blockIdx.x % S);
-        s_ctl[2] = fast;
-        s_ctl[3] = abort_;
-        if (blockIdx.x == 0)
-            __hip_atomic_store(status + 1, fast ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+        lstm_census(a.sync, a.status, S, nwg, a.force_safe, s_ctl);
     __syncthreads();
     const int chain = s_ctl[0], slice = s_ctl[1];
     if (s_ctl[3] || chain >= a.nchains) // aborted, or an XCD / block range with no chain to run
