@@ -85,6 +85,14 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
  * closer than) the fp32-MFMA kernel's, at 2.7x less matrix-core time (csrc/gemm_bf16x3.h, tools/gemm_accuracy.py).
  * UMX_CREATE_GEMM_F32 (environment UMX_GEMM=f32) selects the fp32-MFMA kernels (exact fp32 FMA chain) instead. */
 #define UMX_CREATE_GEMM_F32 0x4u
+/* u8-resident weights (fc1, W_ih; W_hh in the batched LSTM kernel) on the bf16 matrix cores: q - 128 is an integer in
+ * [-128, 127] and EXACT in bf16, so by default the weight is ONE bf16 term (three products with the split activation
+ * instead of six) and the affine map of model.cpp:610-616 is applied to the accumulated sum:
+ *     sum_k a_k (q_k s + o) = s sum_k a_k (q_k - 128) + (o + 128 s) sum_k a_k.
+ * The reference rounds q*s+o to fp32 per weight first; the two differ by exactly that rounding (~1e-7 of the dot
+ * product, the size of one fp32 rounding of the sum).  UMX_CREATE_U8_DEQUANT (environment UMX_U8=dequant) keeps the
+ * per-weight form (dequantise, split in three, six products): bit-identical to UMX_CREATE_DEQUANTISE_AT_LOAD. */
+#define UMX_CREATE_U8_DEQUANT 0x20u
 int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 /* Track batching.  The reference is one track per process (umx.cpp:26-97) and its LSTM is one

@@ -22,15 +22,19 @@ _fp = C.POINTER(C.c_float)
 
 
 def build(force=False):
-    """make -C oracle (g++ only; seconds)."""
-    if force or not (HERE / "liboracle.so").exists() or not (HERE / "liboracle_fast.so").exists() \
-            or (HERE / "umx_oracle.cpp").stat().st_mtime > (HERE / "liboracle.so").stat().st_mtime:
+    """make -C oracle (g++ only; seconds).  Libraries that exist are rebuilt when stale only in the build container
+    (where /root/reference exists); on the GPU box the prebuilt files that travelled with the snapshot are used as
+    they are -- importing the checker never compiles anything there unless a library is missing altogether."""
+    missing = not (HERE / "liboracle.so").exists() or not (HERE / "liboracle_fast.so").exists()
+    stale = not missing and Path("/root/reference").exists() and \
+        max((HERE / f).stat().st_mtime for f in ("umx_oracle.cpp", "umx_oracle.h")) > (HERE / "liboracle.so").stat().st_mtime
+    if force or missing or stale:
         subprocess.check_call(["make", "-C", str(HERE)], stdout=subprocess.DEVNULL)
 
 
 class Taps(C.Structure):
     _fields_ = [("spec", _fp), ("mix_mag", _fp), ("x", _fp), ("fc1_out", _fp * 4),
-                ("lstm_out", _fp * 4), ("mask", _fp * 4), ("target_mag", _fp * 4), ("y", _fp * 4)]
+                ("lstm_out", _fp * 4), ("mask", _fp * 4), ("target_mag", _fp * 4), ("y", _fp * 4), ("fc2_out", _fp * 4)]
 
 
 def _load(fast=False):
@@ -59,6 +63,7 @@ def _load(fast=False):
     lib.oracle_stream_state_floats.argtypes = [C.c_int]
     lib.oracle_lstm_forward.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int, _fp, _fp]
     lib.oracle_target_network.argtypes = [C.c_void_p, C.c_int, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp]
+    lib.oracle_target_network_ex.argtypes = [C.c_void_p, C.c_int, _fp, _fp, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp]
     lib.oracle_wiener.argtypes = [_fp, C.POINTER(_fp), C.c_int, C.POINTER(_fp)]
     lib.oracle_umx_inference.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, _fp, C.POINTER(_fp),
                                          C.c_int, C.POINTER(Taps)]
@@ -222,6 +227,20 @@ def lstm_forward(model, target, x, state):
     return out
 
 
+def target_network(model, target, x, mix_mag, state):
+    """inference.cpp:70-186 for one target.  x (T,2974), mix_mag [2,T,B], state = that target's [3][2][2][H/2] block
+    (updated in place) -> dict of fc1 / lstm / fc2 (T,H), mask (T,4098), target_mag [2,T,B]."""
+    x = np.ascontiguousarray(x, np.float32)
+    T, H = x.shape[0], model.hidden
+    mm = np_to_cm(np.asarray(mix_mag, np.float32))
+    o = {k: np.empty(n, np.float32) for k, n in (("fc1", T * H), ("lstm", T * H), ("fc2", T * H), ("mask", T * 2 * NB),
+                                                ("target_mag", 2 * T * NB))}
+    lib(model.fast).oracle_target_network_ex(model.h, target, _p(x), _p(mm), T, _p(state), _p(o["fc1"]), _p(o["lstm"]),
+                                             _p(o["fc2"]), _p(o["mask"]), _p(o["target_mag"]))
+    return {"fc1": o["fc1"].reshape(T, H), "lstm": o["lstm"].reshape(T, H), "fc2": o["fc2"].reshape(T, H),
+            "mask": o["mask"].reshape(T, 2 * NB), "target_mag": cm_to_np(o["target_mag"], T)}
+
+
 def wiener(spec, target_mags):
     """spec complex [2,T,B], target_mags 4 x [2,T,B] -> 4 x complex [2,T,B]."""
     T = spec.shape[1]
@@ -251,7 +270,7 @@ def umx_inference(model, wave, n_buf=None, state=None, flags=0, want_taps=False)
         keep["mix_mag"] = np.empty(2 * T * NB, np.float32)
         keep["x"] = np.empty(T * 2 * CROP, np.float32)
         taps.spec, taps.mix_mag, taps.x = _p(keep["spec"]), _p(keep["mix_mag"]), _p(keep["x"])
-        for name, sz in (("fc1_out", T * H), ("lstm_out", T * H), ("mask", T * 2 * NB),
+        for name, sz in (("fc1_out", T * H), ("lstm_out", T * H), ("fc2_out", T * H), ("mask", T * 2 * NB),
                          ("target_mag", 2 * T * NB), ("y", 4 * T * NB)):
             keep[name] = [np.empty(sz, np.float32) for _ in range(4)]
             arr = getattr(taps, name)
@@ -269,6 +288,7 @@ def umx_inference(model, wave, n_buf=None, state=None, flags=0, want_taps=False)
         "x": keep["x"].reshape(T, 2 * CROP),
         "fc1_out": [k.reshape(T, H) for k in keep["fc1_out"]],
         "lstm_out": [k.reshape(T, H) for k in keep["lstm_out"]],
+        "fc2_out": [k.reshape(T, H) for k in keep["fc2_out"]],
         "mask": [k.reshape(T, 2 * NB) for k in keep["mask"]],
         "target_mag": [cm_to_np(k, T) for k in keep["target_mag"]],
         "y": [cm_to_np(k, T, True) for k in keep["y"]],

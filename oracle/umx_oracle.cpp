@@ -681,6 +681,13 @@ extern "C" void oracle_target_network(const oracle_model *m, int target, const f
                                       const float *mix_mag, int T, float *state, float *fc1_out,
                                       float *lstm_out, float *mask, float *target_mag)
 {
+    oracle_target_network_ex(m, target, x, mix_mag, T, state, fc1_out, lstm_out, nullptr, mask, target_mag);
+}
+
+extern "C" void oracle_target_network_ex(const oracle_model *m, int target, const float *x,
+                                         const float *mix_mag, int T, float *state, float *fc1_out,
+                                         float *lstm_out, float *fc2_out, float *mask, float *target_mag)
+{
     const int H = m->hidden;
     /* inference.cpp:75-83 with the duplicated mean/scale of model.cpp:240-264 (F8 order) */
     std::vector<float> xin((size_t)T * NIN);
@@ -728,6 +735,8 @@ extern "C" void oracle_target_network(const oracle_model *m, int target, const f
                     std::max(0.0f, ((y - rm[j]) / sqrtf(rv[j] + 1e-5f)) * w[j] + b[j]);
             }
     }
+    if (fc2_out)
+        memcpy(fc2_out, a2.data(), sizeof(float) * a2.size());
     /* fc3 :143; bn3 :148-156 (no activation); output scale + relu :161-166 */
     std::vector<float> a3((size_t)T * NOUT);
     matmul_wt(a2.data(), m->p(target, T_FC3_W), a3.data(), T, H, NOUT);
@@ -944,9 +953,9 @@ extern "C" void oracle_umx_inference(const oracle_model *m, const float *audio, 
         if (skip & (1 << tg))
             continue;
         tl_inner = inner;
-        oracle_target_network(m, tg, x.data(), mix_mag.data(), T, state + (size_t)tg * 12 * Hl,
-                              taps ? taps->fc1_out[tg] : nullptr, taps ? taps->lstm_out[tg] : nullptr,
-                              taps ? taps->mask[tg] : nullptr, tm[tg].data());
+        oracle_target_network_ex(m, tg, x.data(), mix_mag.data(), T, state + (size_t)tg * 12 * Hl,
+                                 taps ? taps->fc1_out[tg] : nullptr, taps ? taps->lstm_out[tg] : nullptr,
+                                 taps ? taps->fc2_out[tg] : nullptr, taps ? taps->mask[tg] : nullptr, tm[tg].data());
     }
     if (taps)
         for (int tg = 0; tg < 4; ++tg)
@@ -1023,7 +1032,9 @@ extern "C" void oracle_shift_inference(const oracle_model *m, const float *audio
                                        int segment_samples, int offset, float *const *out, int flags)
 {
     const int max_shift = (int)(0.5f * 44100); /* umx.cpp:112-113 */
-    const int L2 = length + max_shift - offset; /* umx.cpp:120-122 */
+    /* umx.cpp:120-122: length + max_shift - offset; the reference then writes [offset, offset + length), out of
+     * bounds for offset > max_shift / 2 (never reached by its unseeded rand(): 4033) -- sized to hold the block */
+    const int L2 = length + std::max(max_shift - offset, offset);
     std::vector<float> shifted((size_t)2 * L2, 0.0f);
     memcpy(shifted.data() + (size_t)2 * offset, audio, sizeof(float) * 2 * (size_t)length);
     std::vector<std::vector<float>> o(4, std::vector<float>((size_t)2 * L2));

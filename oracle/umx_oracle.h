@@ -85,6 +85,10 @@ void oracle_lstm_forward(const oracle_model *m, int target, const float *input, 
 void oracle_target_network(const oracle_model *m, int target, const float *x, const float *mix_mag,
                            int T, float *state, float *fc1_out, float *lstm_out, float *mask,
                            float *target_mag);
+/* the same with the fc2/bn2/relu output (T x H, inference.cpp:127-140) as one more optional tap */
+void oracle_target_network_ex(const oracle_model *m, int target, const float *x, const float *mix_mag,
+                              int T, float *state, float *fc1_out, float *lstm_out, float *fc2_out,
+                              float *mask, float *target_mag);
 
 /* wiener.cpp:92-425.  mix_spec ColMajor (2,T,2049) complex (modified in place exactly like the
  * reference: divided by max_abs); target_mags: 4 x ColMajor (2,T,2049); y_out: 4 x complex. */
@@ -103,6 +107,7 @@ typedef struct
     float *mask[4];       /* (T x 4098) */
     float *target_mag[4]; /* (2,T,2049) ColMajor */
     float *y[4];          /* (2,T,2049) complex ColMajor, Wiener output */
+    float *fc2_out[4];    /* (T x H), may be NULL */
 } oracle_taps;
 void oracle_umx_inference(const oracle_model *m, const float *audio, int n, int n_buf,
                           float *state, float *const *out, int flags, oracle_taps *taps);

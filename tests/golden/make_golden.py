@@ -9,6 +9,12 @@ in this container -- they pin the oracle (oracle/umx_oracle.cpp) against restate
   lstm_torch.npz   torch.nn.LSTM(H, H/2, 3 layers, bidirectional) incl. carried (h, c) state (F3)
   dense_torch.npz  torch Linear(bias=False) + BatchNorm1d.eval() stack of inference.cpp:75-185
   wiener_f64.npz   numpy float64 restatement of wiener.cpp:92-425 incl. F5 / F6, subset of bins
+  target_network_f64.npz  the WHOLE per-target network of inference.cpp:75-185 in torch float64: x*scale+mean (F8) ->
+                   fc1/bn1/tanh -> 3-layer BiLSTM from a non-zero carried state -> [fc1|lstm] -> fc2/bn2/relu -> fc3/bn3
+                   -> *output_scale+output_mean, relu -> mask x mix_mag; every stage is stored
+  split_f64.npz    numpy float64 restatement of split_inference's chunking, triangular transition weights, weighted
+                   overlap-add and normalisation (umx.cpp:181-273, sum_weight zeroed = F4 fixed) and of
+                   shift_inference's padding/crop (umx.cpp:115-147) around a known per-segment function
 Only seeds + expected outputs are stored; inputs are regenerated from the seed by the tests.
 gspi_mono.wav / gspi_stereo.wav are the reference's own test data files (test/data/), copied as data.
 """
@@ -92,8 +98,109 @@ def wiener_f64(X, mags, eps=1e-10, scale=10.0):
     return out
 
 
+def target_network_f64(wt, H, x, mix_mag, state):
+    """inference.cpp:75-185 for one target in torch float64.  wt: that target's tensors (fp32 arrays), x (T,2974),
+    mix_mag (2,T,2049), state [3][2][2][H/2] (h, c per layer and direction) -> dict of stages + the new state."""
+    f = lambda a: torch.from_numpy(np.asarray(a, np.float64))  # noqa: E731
+    with torch.no_grad():
+        xs = f(x) * f(np.tile(wt["input_scale"], 2)) + f(np.tile(wt["input_mean"], 2))  # inference.cpp:78-83 (F8)
+
+        def bn(y, name):  # inference.cpp:93-97: ((y - mean) / sqrt(var + 1e-5)) * weight + bias
+            return (y - f(wt[name + ".running_mean"])) / torch.sqrt(f(wt[name + ".running_var"]) + 1e-5) * f(wt[name + ".weight"]) \
+                + f(wt[name + ".bias"])
+        a1 = torch.tanh(bn(xs @ f(wt["fc1.weight"]).T, "bn1"))
+        lstm = torch.nn.LSTM(H, H // 2, num_layers=3, bidirectional=True).double()
+        lstm.load_state_dict({f"{wn}_l{l}{sfx}": f(wt[f"lstm.{wn}_l{l}{sfx}"]) for l in range(3) for sfx in ("", "_reverse")
+                              for wn in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")})
+        st = f(state).reshape(3, 2, 2, H // 2)
+        h0, c0 = st[:, :, 0].reshape(6, 1, H // 2).contiguous(), st[:, :, 1].reshape(6, 1, H // 2).contiguous()
+        lo, (hn, cn) = lstm(a1[:, None, :], (h0, c0))  # lstm.cpp:101-179, state index layer*2+dir, gates i|f|g|o
+        lo = lo[:, 0]
+        a2 = torch.relu(bn(torch.cat([a1, lo], dim=1) @ f(wt["fc2.weight"]).T, "bn2"))  # inference.cpp:118-140
+        a3 = bn(a2 @ f(wt["fc3.weight"]).T, "bn3")  # inference.cpp:143-156
+        mask = torch.relu(a3 * f(np.tile(wt["output_scale"], 2)) + f(np.tile(wt["output_mean"], 2)))  # :161-166
+        mm = f(mix_mag)
+        tm = torch.stack([mask[:, :NB] * mm[0], mask[:, NB:] * mm[1]])  # inference.cpp:173-183
+        new_state = torch.stack([hn[:, 0].reshape(3, 2, H // 2), cn[:, 0].reshape(3, 2, H // 2)], dim=2)
+    return {"fc1": a1.numpy(), "lstm": lo.numpy(), "fc2": a2.numpy(), "mask": mask.numpy(), "target_mag": tm.numpy(),
+            "state": new_state.numpy()}
+
+
+def transition_weight_f64(N):
+    """umx.cpp:197-206: 1..N/2 then N/2..1, divided by the maximum, ^TRANSITION_POWER (= 1)."""
+    half = N // 2
+    w = np.concatenate([np.arange(1, half + 1), np.arange(N - half, 0, -1)]).astype(np.float64)
+    return w / w.max()
+
+
+def split_f64(audio, N, segment_fn):
+    """umx.cpp:152-295 (sum_weight zero-initialised, F4): audio (2,L) float64; segment_fn(chunk (2,n), index) -> 4 x (2,n)."""
+    L = audio.shape[1]
+    stride = int((1 - 0.25) * N)  # umx.cpp:181
+    w = transition_weight_f64(N)
+    out = np.zeros((4, 2, L))
+    sw = np.zeros(L)
+    offs = []
+    for i, off in enumerate(range(0, L, stride)):
+        n = min(N, L - off)  # umx.cpp:214-217
+        stems = segment_fn(audio[:, off:off + n], i)
+        for t in range(4):
+            out[t, :, off:off + n] += w[:n] * stems[t]  # umx.cpp:243-253 (weight index = k % chunk_length, k < n)
+        sw[off:off + n] += w[:n]
+        offs.append(off)
+    return out / sw, sw, offs  # umx.cpp:264-273
+
+
+def shift_f64(audio, N, offset, segment_fn, max_shift=22050):
+    """umx.cpp:99-150: delay by `offset` inside a zero buffer of length L + max_shift - offset, split, crop.  (The
+    reference's buffer is too short for its own block write when offset > max_shift / 2; sized to hold it.)"""
+    L = audio.shape[1]
+    buf = np.zeros((2, L + max(max_shift - offset, offset)))
+    buf[:, offset:offset + L] = audio
+    out, _, _ = split_f64(buf, N, segment_fn)
+    return out[:, :, offset:offset + L]
+
+
+def pseudo_segment(chunk, i):
+    """A known stand-in for umx_inference in the driver goldens: stem t = (t+1) * chunk + 0.001 * (i+1) * ramp."""
+    n = chunk.shape[1]
+    ramp = np.linspace(-1.0, 1.0, n) if n > 1 else np.zeros(1)
+    return [(t + 1) * chunk + 0.001 * (i + 1) * ramp for t in range(4)]
+
+
+def new_goldens(pkg):
+    # ---- 6. the whole target network in float64, from a non-zero carried state
+    H, T, tg = 64, 6, 3
+    W = pkg.ggml.synth_weights(H, seed=606)
+    rng = np.random.default_rng(607)
+    x = (np.abs(rng.standard_normal((T, 2974))) * 20).astype(np.float32)
+    mix = (np.abs(rng.standard_normal((2, T, NB))) * 30).astype(np.float32)
+    state = (rng.standard_normal(12 * (H // 2)) * 0.3).astype(np.float32)
+    g = target_network_f64(W[tg], H, x, mix, state)
+    np.savez_compressed(HERE / "target_network_f64.npz", hidden=H, T=T, target=tg, wseed=606, xseed=607,
+                        fc1=g["fc1"].astype(np.float32), lstm=g["lstm"].astype(np.float32), fc2=g["fc2"].astype(np.float32),
+                        mask=g["mask"].astype(np.float32), target_mag=g["target_mag"].astype(np.float32),
+                        state=g["state"].astype(np.float32).ravel())
+    # ---- 7. segment drivers in float64 around a known per-segment function
+    N = 4096
+    rng = np.random.default_rng(708)
+    L = int(N * 3.4)
+    audio = rng.uniform(-1, 1, (2, L)).astype(np.float32)
+    out, sw, offs = split_f64(audio.astype(np.float64), N, pseudo_segment)
+    # shift_inference with the reference's constants: its unseeded offset 4033, and one beyond max_shift / 2 (where
+    # the reference overruns its buffer; see shift_f64)
+    sh = shift_f64(audio.astype(np.float64)[:, :N // 3], N, 4033, pseudo_segment)
+    sh2 = shift_f64(audio.astype(np.float64)[:, :N // 3], N, 20000, pseudo_segment)
+    np.savez_compressed(HERE / "split_f64.npz", seed=708, N=N, L=L, weight=transition_weight_f64(N).astype(np.float32),
+                        sum_weight=sw[::5].astype(np.float32), offsets=np.array(offs), every=5, out=out[:, :, ::5].astype(np.float32),
+                        shift_len=N // 3, shift_out_4033=sh[:, :, ::3].astype(np.float32), shift_out_20000=sh2[:, :, ::3].astype(np.float32))
+    print("new golden fixtures written")
+
+
 def main():
     pkg = ge.load_package()
+    if len(sys.argv) > 1 and sys.argv[1] == "new":  # only the fixtures added in round 2
+        return new_goldens(pkg)
     # ---- 1. float64 STFT / iSTFT
     rng = np.random.default_rng(101)
     n, n_buf = 6000, 8192
@@ -156,6 +263,7 @@ def main():
     bins = np.array([0, 1, 2, 7, 100, 511, 1024, 1486, 1487, 2000, 2047, 2048])
     np.savez_compressed(HERE / "wiener_f64.npz", seed=305, T=T, bins=bins,
                         y=np.stack([y[:, :, bins] for y in yy]).astype(np.complex64))
+    new_goldens(pkg)
     print("golden fixtures written to", HERE)
 
 

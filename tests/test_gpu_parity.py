@@ -214,23 +214,31 @@ def test_carry_mode_two_processes_one_gpu(pkg, model_small, tmp_path):
 
 
 def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_path):
-    """BASELINE config 5: u8/u16 matrices stay in HBM and are dequantised in the GEMM B-tile staging and the
-    LSTM W_hh register load (q*scale+offset, model.cpp:610-616): same bits as dequantising at load time,
-    a third of the weight memory; persistent and per-step LSTM drivers, small and UMX-L-sized hidden."""
+    """BASELINE config 5: u8/u16 matrices stay in HBM, a third of the weight memory.  With u8_dequant they are
+    dequantised per element in the GEMM B-tile staging and the LSTM W_hh register load (q*scale+offset,
+    model.cpp:610-616): same bits as dequantising at load time; persistent and per-step LSTM drivers, small and
+    UMX-L-sized hidden.  The default treats u8 GEMM weights as exact bf16 integers and applies the affine map to
+    the sum (three matrix-core products instead of six): equal to that within fp32 rounding, not bitwise."""
     path, om, targets = model_small
     N = 16 * 1024
     waves = [pkg.ggml.synth_audio(N, 400 + i) for i in range(2)]
     ref = pkg.Engine(targets, 128, N, quantised_resident=False)
-    qr = pkg.Engine(targets, 128, N)  # the default
+    qr = pkg.Engine(targets, 128, N, u8_dequant=True)
+    qx = pkg.Engine(targets, 128, N)  # the default
     assert qr.weight_bytes() * 3.5 < ref.weight_bytes()  # u8/u16 against three bf16 planes (+ fp32 W_hh)
+    assert qx.weight_bytes() == qr.weight_bytes()
     for flags in (0, pkg.FLAG_LSTM_STEPWISE):
         ref.stream_reset()
         qr.stream_reset()
+        qx.stream_reset()
         for w in waves:
-            a, b = ref.infer_segment(w, flags), qr.infer_segment(w, flags)
+            a, b, c = ref.infer_segment(w, flags), qr.infer_segment(w, flags), qx.infer_segment(w, flags)
             for t in range(4):
                 assert (a[t] == b[t]).all(), (flags, t)
+                assert 0 < np.abs(a[t] - c[t]).max() < 1e-5, (flags, t)  # both sit ~1e-6 from the oracle
         assert (ref.stream_get() == qr.stream_get()).all()
+        assert rel_l2(qx.stream_get(), ref.stream_get()) < 2e-5
+    qx.close()
     # fp32 views cannot stay quantised: the flag is then a no-op, not an error
     f32 = pkg.Engine(targets, 128, N, quantised=False)
     assert f32.weight_bytes() == ref.weight_bytes()
@@ -239,7 +247,7 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     H, N = 1024, 24 * 1024
     p = str(tmp_path / "m.bin")
     pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=31), H, compress=False)
-    ref, qr = pkg.Engine.from_file(p, N, quantised_resident=False), pkg.Engine.from_file(p, N)
+    ref, qr = pkg.Engine.from_file(p, N, quantised_resident=False), pkg.Engine.from_file(p, N, u8_dequant=True)
     assert 130e6 < qr.weight_bytes() < 150e6 and 600e6 < ref.weight_bytes() < 640e6
     f32 = pkg.Engine.from_file(p, N, gemm="f32", quantised_resident=False)
     assert 440e6 < f32.weight_bytes() < 470e6

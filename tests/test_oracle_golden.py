@@ -107,3 +107,81 @@ def test_inference_pipeline_shapes_and_state(pkg, po):
     # a second segment gives a different result because of the carried state
     outs2, _ = po.umx_inference(m, wave, n_buf=n_buf, state=st)
     assert np.abs(outs2[0] - outs[0]).max() > 1e-6
+
+
+def test_whole_target_network_vs_float64_torch(pkg, po):
+    """inference.cpp:75-185 end to end for one target -- input scale (F8 order), fc1/bn1/tanh, the 3-layer BiLSTM from a
+    NON-ZERO carried state, skip concat, fc2/bn2/relu, fc3/bn3, output scale + relu, mask x mix magnitude -- against an
+    independent torch float64 evaluation (tests/golden/make_golden.py::target_network_f64).  Every stage is pinned,
+    including fc2 / fc3 / bn3 / output scaling, which the earlier goldens did not reach."""
+    g = np.load(GOLD / "target_network_f64.npz")
+    H, T, tg = int(g["hidden"]), int(g["T"]), int(g["target"])
+    m = po.Model.from_arrays(H, _weights(pkg, int(g["wseed"]), H))
+    rng = np.random.default_rng(int(g["xseed"]))
+    x = (np.abs(rng.standard_normal((T, 2974))) * 20).astype(np.float32)
+    mix = (np.abs(rng.standard_normal((2, T, 2049))) * 30).astype(np.float32)
+    state = (rng.standard_normal(12 * (H // 2)) * 0.3).astype(np.float32)
+    got = po.target_network(m, tg, x, mix, state)
+    assert np.abs(got["fc1"] - g["fc1"]).max() < 5e-6
+    assert np.abs(got["lstm"] - g["lstm"]).max() < 5e-6
+    assert np.abs(state - g["state"]).max() < 5e-6  # the carried (h, c) after the segment
+    for k in ("fc2", "mask", "target_mag"):
+        assert rel_l2(got[k], g[k]) < 2e-6, k
+    assert (got["mask"] >= 0).all() and (got["mask"] == 0).any() and (got["mask"] > 0).any()  # the relu is exercised
+
+
+def _pseudo_segment(chunk, i):
+    """the known per-segment function of the driver goldens (make_golden.py::pseudo_segment), in float32"""
+    n = chunk.shape[1]
+    ramp = np.linspace(-1.0, 1.0, n) if n > 1 else np.zeros(1)
+    return [((t + 1) * chunk.astype(np.float64) + 0.001 * (i + 1) * ramp).astype(np.float32) for t in range(4)]
+
+
+def test_segment_drivers_vs_float64_numpy(pkg, po):
+    """split_inference's chunking, triangular weights, weighted overlap-add and normalisation (umx.cpp:181-273) and
+    shift_inference's delay / crop (umx.cpp:115-147) against a numpy float64 restatement around a known per-segment
+    function: pins the C++17 host drivers (host/split.cpp) directly, and the oracle's drivers through its own
+    per-segment outputs."""
+    g = np.load(GOLD / "split_f64.npz")
+    N, L, ev = int(g["N"]), int(g["L"]), int(g["every"])
+    audio = np.random.default_rng(int(g["seed"])).uniform(-1, 1, (2, L)).astype(np.float32)
+    # transition weights and the segment plan
+    hl = pkg.host_lib()
+    w = np.array([hl.umx_transition_weight(k, N, N) for k in range(N)], np.float32)
+    assert np.abs(w - g["weight"]).max() < 1e-7
+    offs, lens = pkg.segment_plan(L, N)
+    assert offs == list(g["offsets"]) and lens[-1] == L - offs[-1] and all(n == N for n in lens[:-1])
+    # host driver with the known per-segment function
+    calls = []
+
+    def seg(chunk):
+        calls.append(chunk.shape[1])
+        return _pseudo_segment(chunk, len(calls) - 1)
+    be = pkg.make_backend(seg)
+    out = pkg.split_inference(be, audio, N)
+    assert calls == lens
+    for t in range(4):
+        assert np.abs(out[t][:, ::ev] - g["out"][t]).max() < 2e-6, t
+    # shift_inference: the reference's own offset, and one beyond max_shift / 2 (a buffer overrun in the reference)
+    n3 = int(g["shift_len"])
+    for off in (4033, 20000):
+        calls.clear()
+        sh = pkg.shift_inference(be, audio[:, :n3], N, offset=off)
+        for t in range(4):
+            assert np.abs(sh[t][:, ::3] - g[f"shift_out_{off}"][t]).max() < 2e-6, (off, t)
+    # the oracle's split driver: its own per-segment outputs (carried state) blended with the golden weights in float64
+    H = 64
+    m = po.Model.from_arrays(H, _weights(pkg, 7, H))
+    st = po.stream_state(H)
+    acc, sw = np.zeros((4, 2, L)), np.zeros(L)
+    wt = g["weight"].astype(np.float64)
+    for off, n in zip(offs, lens):
+        stems, _ = po.umx_inference(m, audio[:, off:off + n], n_buf=N, state=st)
+        for t in range(4):
+            acc[t, :, off:off + n] += wt[:n] * stems[t]
+        sw[off:off + n] += wt[:n]
+    ref = acc / sw
+    got = po.split_inference(m, audio, N)
+    for t in range(4):
+        assert np.abs(got[t] - ref[t]).max() < 2e-6, t
+    assert np.abs(sw[::ev] - g["sum_weight"]).max() < 1e-6

@@ -133,6 +133,7 @@ CREATE_QUANTISED_RESIDENT = 0x1
 CREATE_GEMM_F32 = 0x4
 CREATE_DEQUANTISE_AT_LOAD = 0x8
 CREATE_LSTM_BATCHED = 0x10
+CREATE_U8_DEQUANT = 0x20
 MAX_TRACKS = 16
 
 HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "umx_hip_n_tracks", "umx_hip_lstm_is_batched",
@@ -182,7 +183,7 @@ class Engine:
     the streaming LSTM state carries over until `stream_reset`."""
 
     def __init__(self, targets, hidden, segment_samples=SEGMENT_SAMPLES, device=0, quantised=True,
-                 quantised_resident=True, gemm=None, tracks=1, lstm_batched=False):
+                 quantised_resident=True, gemm=None, tracks=1, lstm_batched=False, u8_dequant=False):
         """quantised: hand the file's u8/u16 bytes (+ scale/offset) to the engine instead of fp32 arrays;
         quantised_resident: keep them that way in HBM (the default; BASELINE config 5) or expand them at load;
         gemm: "bf16x3" (default: three-term bf16 split on the bf16 matrix cores) or "f32" (fp32 MFMA);
@@ -194,7 +195,8 @@ class Engine:
         rc = self.lib.umx_hip_create_tracks(C.byref(h), device, hidden, segment_samples, views, len(views),
                                             (0 if quantised_resident else CREATE_DEQUANTISE_AT_LOAD) |
                                             (CREATE_GEMM_F32 if (gemm or os.environ.get("UMX_GEMM", "bf16x3")) == "f32" else 0) |
-                                            (CREATE_LSTM_BATCHED if lstm_batched else 0), tracks)
+                                            (CREATE_LSTM_BATCHED if lstm_batched else 0) |
+                                            (CREATE_U8_DEQUANT if (u8_dequant or os.environ.get("UMX_U8") == "dequant") else 0), tracks)
         if rc != UMX_OK:
             raise UmxError(rc, self.lib.umx_hip_last_error(None).decode())
         self.h = h
@@ -205,10 +207,10 @@ class Engine:
 
     @classmethod
     def from_file(cls, path, segment_samples=SEGMENT_SAMPLES, device=0, quantised_resident=True, gemm=None, tracks=1,
-                  lstm_batched=False, quantised=True):
+                  lstm_batched=False, quantised=True, u8_dequant=False):
         hidden, targets = ggml.read_model(path)
         return cls(targets, hidden, segment_samples, device, quantised=quantised, quantised_resident=quantised_resident,
-                   gemm=gemm, tracks=tracks, lstm_batched=lstm_batched)
+                   gemm=gemm, tracks=tracks, lstm_batched=lstm_batched, u8_dequant=u8_dequant)
 
     def lstm_is_batched(self):
         return bool(self.lib.umx_hip_lstm_is_batched(self.h))

@@ -199,6 +199,8 @@ struct umx_hip_ctx
              unsigned create_flags, int n_tracks);
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
     bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
+    bool u8_dequant = false;      // UMX_CREATE_U8_DEQUANT: u8 weights dequantised per element (model.cpp:610-616) before they
+                                  // are multiplied, instead of exact bf16 integers with the affine map applied to the sum
     unsigned char *whh_q[3] = {}; // u8-resident W_hh (create flag), same layout as whh[]
     float whh_s[3][8] = {}, whh_o[3][8] = {};
     int infer_device(const float *audio_dev, int n, float *const out[4], unsigned flags);
@@ -277,6 +279,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     }
     B = n_tracks;
     lstm_batched = B > 1 || (create_flags & UMX_CREATE_LSTM_BATCHED);
+    u8_dequant = create_flags & UMX_CREATE_U8_DEQUANT;
     if (hidden <= 0 || hidden % 128 != 0 || hidden > 2048)
     {
         set_error("hidden_size must be a positive multiple of 128 (<= 2048)");
@@ -756,7 +759,9 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                                 reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3, BQ_U16>)};
         for (const void *fn : gemms)
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-        const void *bxs[8] = {reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_F32>),
+        const void *bxs[10] = {reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_U8X>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_IH, BQ_U8X>),
+                              reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_F32>),
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_U8>),
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_IH, BQ_F32>),
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_IH, BQ_U8>),
@@ -934,7 +939,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     a.nbp = top > 8 ? 16 : top > 4 ? 8 : top > 2 ? 4 : top > 1 ? 2 : 1;
     a.bulk = a.nbp > 8 ? 8 : 16;
     const size_t lds = lstmb_lds_bytes(a.nbp, a.bulk);
-    const bool wq = whh_q[layer] != nullptr;
+    const bool wq = whh_q[layer] != nullptr && !u8_dequant;
     const void *fn = lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
     void *kargs[] = {&a};
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
@@ -1042,11 +1047,13 @@ void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, con
         switch (mode)
         {
         case G_FC1:
-            if (bq == BQ_U8) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_U8>), BX_LDS_BYTES);
+            if (bq == BQ_U8 && !u8_dequant) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_U8X>), BX_LDS_BYTES);
+            else if (bq == BQ_U8) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_U8>), BX_LDS_BYTES);
             else UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_F32>), BX_LDS_BYTES);
             break;
         case G_IH:
-            if (bq == BQ_U8) UMX_LAUNCH((gemm_bf16x3_kernel<G_IH, BQ_U8>), BX_LDS_BYTES);
+            if (bq == BQ_U8 && !u8_dequant) UMX_LAUNCH((gemm_bf16x3_kernel<G_IH, BQ_U8X>), BX_LDS_BYTES);
+            else if (bq == BQ_U8) UMX_LAUNCH((gemm_bf16x3_kernel<G_IH, BQ_U8>), BX_LDS_BYTES);
             else UMX_LAUNCH((gemm_bf16x3_kernel<G_IH, BQ_F32>), BX_LDS_BYTES);
             break;
         case G_FC2:
@@ -1287,7 +1294,9 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     if (int rc = sync_all())
         return rc;
     const int lead = shift_offset < 0 ? 0 : shift_offset;
-    const long long L2ll = shift_offset < 0 ? (long long)length : (long long)length + UMX_MAX_SHIFT - shift_offset; // umx.cpp:120-122
+    // umx.cpp:120-122: length + max_shift - offset -- which the reference overruns for offset > max_shift / 2 (its
+    // block write is [offset, offset + length)); the same size where the reference is defined, large enough elsewhere
+    const long long L2ll = shift_offset < 0 ? (long long)length : (long long)length + std::max(UMX_MAX_SHIFT - shift_offset, shift_offset);
     if (L2ll > 0x7fffffff / 2)
     {
         set_error("track: too long");
@@ -1552,6 +1561,9 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
     if (const char *e = getenv("UMX_LSTM"))
         if (std::string(e) == "batched")
             cf |= UMX_CREATE_LSTM_BATCHED;
+    if (const char *e = getenv("UMX_U8"))
+        if (std::string(e) == "dequant")
+            cf |= UMX_CREATE_U8_DEQUANT;
     return umx_hip_create_ex(out, device, hidden_size, segment_samples, tensors, n_tensors, cf);
 }
 

@@ -59,6 +59,20 @@ __device__ __forceinline__ void split3(const float (&x)[8], uint4 &p1, uint4 &p2
     p3 = make_uint4(o3[0], o3[1], o3[2], o3[3]);
 }
 
+// 8 u8 weights -> 8 bf16 values q - 128 (integers in [-128, 127] are exact in bf16: the fp32 value's upper half)
+__device__ __forceinline__ uint4 u8x8_to_bf16_centered(unsigned lo, unsigned hi)
+{
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const unsigned src = i < 2 ? lo : hi;
+        const float f0 = (float)((src >> (16 * (i & 1))) & 255u) - 128.0f, f1 = (float)((src >> (16 * (i & 1) + 8)) & 255u) - 128.0f;
+        o[i] = (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // host-side twin of split3 (weights at load time); round-to-nearest-even like v_cvt_pk_bf16_f32
 __host__ inline unsigned short bf16_rne_bits(float f)
 {
@@ -85,6 +99,15 @@ __host__ inline void split3_host(float x, unsigned short &p1, unsigned short &p2
     p3 = bf16_rne_bits(r2);
 }
 
+// BQ_U8X (u8-resident weights, the default for them): q - 128 is an integer in [-128, 127], EXACT in bf16, so the
+// weight needs ONE plane and the product three MFMAs (a1 + a2 + a3).(q - 128) instead of six; the affine map of
+// model.cpp:610-616 moves out of the dot product:
+//     sum_k a_k (q_k s + o) = s * sum_k a_k (q_k - 128) + (o + 128 s) * sum_k a_k
+// The row sums of A come for free from the staging threads (each already holds its 8 values of the K tile).  Half
+// the matrix-core time, a third less LDS traffic, no dequantise-and-split VALU work for B.  Against the reference's
+// per-weight rounding of q*s+o this differs by that rounding: ~1e-7 of the dot product, one fp32 rounding of the
+// sum (tools/gemm_accuracy.py).  UMX_CREATE_U8_DEQUANT selects BQ_U8 (dequantise, then split: bit-identical to
+// expanding the weights at load time).
 // BQ_F32: GemmTarget::Bq = the three planes [3][N][K] (bf16 bits) split at load time.
 // BQ_U8 / BQ_U16 (quantised-resident weights, config 5): GemmTarget::Bq = the file's bytes [N][K]; the staging
 // code dequantises (q*scale+offset, model.cpp:610-616) and splits on the fly -- the same three planes bit for
@@ -116,7 +139,8 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
     const int st_row = (tid & 31) + 32 * (tid >> 6), st_half = (tid >> 5) & 1;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tg.A), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(tg.Bq), 0, 0x7fffffff, 0x00020000);
-    constexpr int BEL = BQ == BQ_U8 ? 1 : 2; // bytes per resident B element (bf16 plane, u16 or u8)
+    constexpr bool U8 = BQ == BQ_U8 || BQ == BQ_U8X;
+    constexpr int BEL = U8 ? 1 : 2; // bytes per resident B element (bf16 plane, u16 or u8)
     const int voffA = (st_row * lda + st_half * 8) * 4, voffB = (st_row * K + st_half * 8) * BEL;
     const int soffA0 = m0 * lda * 4, soffB0 = n0 * K * BEL;
     const int plane_stride = args.N * K * 2; // bytes between pre-split B planes
@@ -137,7 +161,7 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
             rb2 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, soffB0 + (k0)*2 + plane_stride, 0));     \
             rb3 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, soffB0 + (k0)*2 + 2 * plane_stride, 0)); \
         }                                                                                              \
-        else if (BQ == BQ_U8)                                                                          \
+        else if (U8)                                                                                   \
         {                                                                                              \
             const uint2 q = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsB, voffB, soffB0 + (k0), 0)); \
             rb1.x = q.x;                                                                               \
@@ -163,12 +187,16 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
             a1 = scale_shift(a1, rs1, rm1);                                                            \
         }                                                                                              \
         const float xs[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};                          \
+        if (BQ == BQ_U8X) /* this thread's share of the row sum of A, fixed order */                   \
+            rowsum += ((xs[0] + xs[1]) + (xs[2] + xs[3])) + ((xs[4] + xs[5]) + (xs[6] + xs[7]));       \
         uint4 p1, p2, p3;                                                                              \
         split3(xs, p1, p2, p3);                                                                        \
         *reinterpret_cast<uint4 *>(base) = p1;                                                         \
         *reinterpret_cast<uint4 *>(base + BX_PLANE_BYTES) = p2;                                        \
         *reinterpret_cast<uint4 *>(base + 2 * BX_PLANE_BYTES) = p3;                                    \
-        if (BQ == BQ_F32)                                                                              \
+        if (BQ == BQ_U8X)                                                                              \
+            *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES) = u8x8_to_bf16_centered(rb1.x, rb1.y); \
+        else if (BQ == BQ_F32)                                                                         \
         {                                                                                              \
             *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES) = rb1;                                 \
             *reinterpret_cast<uint4 *>(base + BX_OPERAND_BYTES + BX_PLANE_BYTES) = rb2;                \
@@ -199,6 +227,7 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
     }
 
     floatx16 acc00, acc01, acc10, acc11;
+    float rowsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
     {
@@ -224,7 +253,14 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
 #define BX_COMPUTE(buf)                                                                                \
     {                                                                                                  \
         const int bo = (buf)*BX_BUF_BYTES;                                                             \
-        BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)           \
+        if (BQ == BQ_U8X)                                                                              \
+        {                                                                                              \
+            BX_TERM(2, 0) BX_TERM(1, 0) BX_TERM(0, 0)                                                  \
+        }                                                                                              \
+        else                                                                                           \
+        {                                                                                              \
+            BX_TERM(2, 0) BX_TERM(0, 2) BX_TERM(1, 1) BX_TERM(1, 0) BX_TERM(0, 1) BX_TERM(0, 0)       \
+        }                                                                                              \
     }
 
     BX_GLOAD(0)
@@ -240,6 +276,33 @@ template <int MODE, int BQ> __global__ __launch_bounds__(256, 2) void gemm_bf16x
         __syncthreads();
     }
     BX_COMPUTE((nk - 1) & 1)
+    if (BQ == BQ_U8X)
+    {
+        // acc = sum a (q - 128)  ->  W x = s * acc + (o + 128 s) * rowsum(A).  The two k-halves of every row meet in
+        // the LDS buffer the last tile did not use.
+        float *rs = reinterpret_cast<float *>(bx_smem + (nk & 1) * BX_BUF_BYTES);
+        rs[st_half * 128 + st_row] = rowsum;
+        __syncthreads();
+        const float o2 = bof + 128.0f * bsc;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+            {
+                const int ml = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float add = o2 * (rs[ml] + rs[128 + ml]);
+                if (mi == 0)
+                {
+                    acc00[r] = bsc * acc00[r] + add;
+                    acc01[r] = bsc * acc01[r] + add;
+                }
+                else
+                {
+                    acc10[r] = bsc * acc10[r] + add;
+                    acc11[r] = bsc * acc11[r] + add;
+                }
+            }
+    }
 #undef BX_GLOAD
 #undef BX_SSTORE
 #undef BX_LD

@@ -141,7 +141,8 @@ enum GemmBType
 {
     BQ_F32 = 0,
     BQ_U8 = 1,
-    BQ_U16 = 2
+    BQ_U16 = 2,
+    BQ_U8X = 3 // bf16x3 kernel only: u8 weights as EXACT bf16 integers, affine map applied to the sum (gemm_bf16x3.h)
 };
 
 __device__ __forceinline__ float4 deq_u8x4(unsigned p, float sc, float of)

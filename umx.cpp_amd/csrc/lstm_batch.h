@@ -315,12 +315,6 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 if (step - t_begin > bulk && ((step - t_begin) & (bulk - 1)) == 1)
                     fetch_rows(step - 1 + bulk);
             }
-#if LSTMB_DEFER_OUT
-            // the output row of the PREVIOUS step goes out here, behind the polls: vector memory operations complete
-            // in order, and a store queued in front of the poll loads would sit on the hand-off's critical path
-            if (gate_wave && lane_on && step > t_begin)
-                outp[(size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast; // lstm.cpp:163-164,170-171
-#endif
             if (prof)
                 c1 = clock64();
             floatx4 acc[4], accH = {0.f, 0.f, 0.f, 0.f};
@@ -364,6 +358,12 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                                                   : make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
             }
         }
+#if LSTMB_DEFER_OUT
+        // the output row of the PREVIOUS step goes out here, behind the polls: vector memory operations complete in
+        // order, and a store queued in front of the poll loads would sit on the hand-off's critical path
+        if (gate_wave && lane_on && step > t_begin)
+            outp[(size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast; // lstm.cpp:163-164,170-171
+#endif
         // W_ih x + b_ih of this lane's unit and track (in the ring since at least one barrier ago)
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gate_wave && n < nbp)

@@ -131,7 +131,10 @@ extern "C" int umx_shift_inference(const umx_backend *be, const float *audio, in
         seterr(err, "shift offset must be < 22050");
         return UMX_ERR_ARG;
     }
-    const int L2 = length + max_shift - offset; // umx.cpp:120-122
+    // umx.cpp:120-122 sizes the buffer length + max_shift - offset and then writes [offset, offset + length): past
+    // its end for offset > max_shift / 2 (undefined behaviour in the reference; its unseeded rand() always gives 4033).
+    // Same size wherever the reference is defined, large enough everywhere else.
+    const int L2 = length + std::max(max_shift - offset, offset);
     std::vector<float> shifted((size_t)2 * L2, 0.0f);
     memcpy(shifted.data() + (size_t)2 * offset, audio, sizeof(float) * 2 * (size_t)length);
     std::vector<float> full[4];
