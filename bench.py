@@ -1,18 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- realtime factor of UMX-L 4-stem separation on 60 s segments (BASELINE.json metric).
 
-A "step" = one pass of the hot path (umx_inference, inference.cpp:12-207) over one synthetic 60 s
-stereo segment: STFT -> 4 x [fc1/bn/tanh -> 3-layer BiLSTM -> fc2 -> fc3 -> mask] -> Wiener EM ->
-4 x iSTFT, with the input already resident in HBM and the 4 stems left in HBM.  Consecutive steps
-are consecutive segments of one track: the streaming LSTM state carries over (umx.cpp:167-171).
-The default workload is BASELINE config 3 (4 stems + Wiener, the full umx_inference); --no-wiener
-gives config 2.
+A "step" = one pass of the hot path (umx_inference, inference.cpp:12-207) over one synthetic 60 s stereo segment of
+EVERY track lane of the context: STFT -> 4 x [fc1/bn/tanh -> 3-layer BiLSTM -> fc2 -> fc3 -> mask] -> Wiener EM ->
+4 x iSTFT.  Consecutive steps are consecutive segments of the same tracks: the streaming LSTM state carries over
+(umx.cpp:167-171).  The default workload is BASELINE config 3 (4 stems + Wiener, the full umx_inference) on
+--tracks independent tracks per GPU (default 16: their LSTM recurrences share one matrix-core launch per layer,
+SURVEY 8f-4); --tracks 1 is the single-track, latency-optimised engine; --no-wiener gives config 2, --vocals-only
+config 1.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank separates its own
-independent segments (weak scaling; the path shards by segment/track, no data-path collective);
-barrier + synchronize on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+What the JSON line holds (one line, rank 0):
+  value            audio-seconds per wall-second, whole job, inputs and stems RESIDENT IN HBM (the contract's number)
+  value_pcie       the same K steps with pinned HOST buffers in and out: H2D audio + all kernels + D2H stems inside the
+                   timed region (SURVEY 8(d)'s unit of work), transfers overlapped through the two pipeline slots
+  single_track     the --tracks 1 engine on the same GPU (one track at a time: the latency view)
+  roofline         the dominant kernel by device time: live HIP-event duration per launch (events on the engine's own
+                   streams), algorithmic and issued flops per launch, roof, fraction; `traffic` = HBM bytes per launch
+                   from the rocprofv3 PMC summary named in `traffic_source` (2 x FETCH_SIZE + WRITE_SIZE, gfx950
+                   correction of MI355X_MICROARCH.md) -- read from that file at run time, null if it is absent
+  kernels          the same figures for every kernel family, so each fraction can be recomputed from the line
+  cpu_baseline     the oracle (reference flag set) on this box's host cores, bounded samples: config 3 on all cores
+                   (the headline leg) + `legs` for config 1 / config 3 on one thread and on all cores
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank separates its own independent
+tracks (weak scaling; the path shards by track, no data-path collective); barrier + synchronize on both sides,
+MAX over ranks, rank 0 prints ONE JSON line.  --mode track instead shards ONE track's segments over the ranks
+(BASELINE config 4, exact state carry; see umx.cpp_amd/multigpu.py).
 """
 import argparse
+import csv
+import glob
 import json
 import os
 import sys
@@ -27,76 +44,107 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
 SEG = 60 * 44100
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+NB, KXA, NOUT = 2049, 2974, 4098
 
 
-def algorithmic_work(T, H, wiener=True):
-    """Per-segment algorithmic flops / bytes per stage."""
-    NB, KX, NOUT = 2049, 2974, 4098
+def algorithmic_work(T, H):
+    """Algorithmic flops / bytes of ONE launch of each kernel family for one track lane."""
     gemm = {
-        "fc1": 2.0 * T * KX * H * 4,
-        "lstm_ih": 2.0 * T * H * (4 * H) * 4,          # per layer, both directions, 4 targets
+        "fc1": 2.0 * T * KXA * H * 4,
+        "lstm_ih": 2.0 * T * H * (4 * H) * 4,          # one layer, both directions, 4 targets
         "fc2": 2.0 * T * (2 * H) * H * 4,
         "fc3_mask": 2.0 * T * H * NOUT * 4,
     }
-    rec = 2.0 * T * (H // 2) * (2 * H) * 2 * 4         # per layer: W_hh.h, 2 dirs, 4 targets
-    bytes_ = {
+    rec = 2.0 * T * (H // 2) * (2 * H) * 2 * 4         # one layer: W_hh.h, 2 dirs, 4 targets
+    byt = {
         "stft": 4.0 * (2 * T * 1024 + 2 * T * NB * 2 + 2 * T * NB + T * 2976),
-        "wiener": 4.0 * (4 * (2 * T * NB * 3) + (2 * T * NB * 2 + 4 * 2 * T * NB) + 4 * 2 * T * NB * 2) if wiener
-        else 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * 2 * T * NB * 2),
+        "wiener": 4.0 * (4 * (2 * T * NB * 3) + (2 * T * NB * 2 + 4 * 2 * T * NB) + 4 * 2 * T * NB * 2),
+        "mixphase": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * 2 * T * NB * 2),
         "istft": 4.0 * (4 * 2 * T * NB * 2 + 4 * T * 4096 * 2),
         "ola": 4.0 * (4 * T * 4096 * 2 + 4 * 2 * T * 1024),
     }
-    return gemm, rec, bytes_
+    return gemm, rec, byt
 
 
-def cpu_baseline(pkg, hidden, weights_path, seconds_audio=6.0, threads=None):
-    """Reference-equivalent CPU path (oracle, reference flag set -O3 -march=native -ffast-math) on a
-    bounded sample of the same workload: the first `seconds_audio` of the synthetic track as one
-    segment (same per-frame cost as a 60 s segment; LSTM state zero).  NOT the Eigen binary."""
+def cpu_leg(pkg, weights_path, seconds_audio, threads, flags, label):
+    """The oracle built with the reference's Release flags (-O3 -march=native -ffast-math -fopenmp, per-timestep GEMV
+    LSTM) on the first `seconds_audio` of the synthetic track as one segment; NOT the Eigen binary."""
     po = ge.load_oracle()
-    threads = threads or os.cpu_count()
     po.set_num_threads(threads, fast=True)
     om = po.Model.load(weights_path, fast=True)
     n = int(seconds_audio * 44100)
     wave = pkg.ggml.synth_audio(n, seed=0)
     t0 = time.time()
-    po.umx_inference(om, wave)
+    po.umx_inference(om, wave, flags=flags)
     dt = time.time() - t0
-    return {"value": round(seconds_audio / dt, 4), "unit": "x realtime (audio-sec / wall-sec)", "cores": threads,
-            "kind": "port",
-            "sample": f"first {seconds_audio:g} s of the synthetic track as one segment ({n // 1024 + 1} frames), "
-                      f"4 stems + Wiener, {dt:.1f} s wall; Eigen-equivalent restatement (oracle/, -O3 -march=native "
-                      f"-ffast-math -fopenmp, per-timestep GEMV LSTM), not the Eigen binary"}
+    return {"config": label, "value": round(seconds_audio / dt, 4), "unit": "x realtime (audio-sec / wall-sec)", "cores": threads,
+            "kind": "port", "sample": f"first {seconds_audio:g} s of the synthetic track as one segment ({n // 1024 + 1} frames), "
+                                      f"{dt:.1f} s wall"}
+
+
+def cpu_baseline(pkg, weights_path, seconds_all, seconds_one):
+    ncores = os.cpu_count()
+    legs = [cpu_leg(pkg, weights_path, seconds_all, ncores, 0, "config 3: 4 stems + Wiener"),
+            cpu_leg(pkg, weights_path, seconds_all, ncores, 0x700, "config 1: vocals model only (targets 0-2 skipped)"),
+            cpu_leg(pkg, weights_path, seconds_one, 1, 0, "config 3: 4 stems + Wiener"),
+            cpu_leg(pkg, weights_path, seconds_one, 1, 0x700, "config 1: vocals model only (targets 0-2 skipped)")]
+    head = dict(legs[0])
+    head["sample"] += ("; Eigen-equivalent restatement (oracle/, -O3 -march=native -ffast-math -fopenmp, per-timestep GEMV LSTM, "
+                       "targets x directions threaded), not the Eigen binary")
+    head["legs"] = legs
+    return head
+
+
+def read_traffic(path):
+    """profiles/*pmc_fetch_write_per_kernel.csv -> {kernel name: HBM bytes per launch} (2 x FETCH + WRITE, raw KB)."""
+    out = {}
+    try:
+        for r in csv.reader(open(path)):
+            if len(r) >= 4 and r[0] != "kernel":
+                out[r[0]] = (2.0 * float(r[2]) + float(r[3])) * 1024.0
+    except OSError:
+        pass
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--tracks", type=int, default=16,
+                    help="independent tracks per GPU run together (track lanes, 1..16): one step = one 60 s segment of EVERY "
+                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4)")
+    ap.add_argument("--batched-lstm", action="store_true", help="use the batched LSTM kernel also with --tracks 1")
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--segment-samples", type=int, default=SEG)
-    ap.add_argument("--no-wiener", action="store_true")
+    ap.add_argument("--no-wiener", action="store_true", help="BASELINE config 2 (mixture phase, no Wiener EM)")
+    ap.add_argument("--vocals-only", action="store_true", help="BASELINE config 1 on the GPU (targets 0-2 skipped)")
     ap.add_argument("--stepwise-lstm", action="store_true")
     ap.add_argument("--safe-lstm", action="store_true", help="persistent LSTM kernel without the intra-XCD hand-off")
     ap.add_argument("--lstm-profile", action="store_true", help="print per-phase shader-clock counters of the LSTM kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=15.0)
-    ap.add_argument("--serial", action="store_true", help="sync after every segment (no cross-segment pipelining)")
-    ap.add_argument("--tracks", type=int, default=1,
-                    help="independent tracks per GPU run together (track lanes, 1..16): one step = one 60 s segment of EVERY "
-                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4)")
-    ap.add_argument("--batched-lstm", action="store_true", help="use the batched LSTM kernel also with --tracks 1")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=15.0, help="audio seconds of the all-cores CPU legs")
+    ap.add_argument("--cpu-sample-seconds-1t", type=float, default=1.5, help="audio seconds of the one-thread CPU legs")
+    ap.add_argument("--serial", action="store_true", help="sync after every step (no cross-segment pipelining)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the value_pcie leg")
+    ap.add_argument("--no-single-track", action="store_true", help="skip the single-track (tracks = 1) leg")
     ap.add_argument("--track-seconds", type=float, default=0.0,
                     help="also time a whole track of this length through umx_hip_shift_inference (host buffers in and "
                          "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
+    ap.add_argument("--mode", choices=["segments", "track"], default="segments",
+                    help="track: ONE 600 s track, its segments sharded over the ranks with exact LSTM state carry (config 4)")
     ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=None,
                     help="dense-stack GEMM flavour: bf16x3 (default; three-term bf16 split, fp32-class accuracy) or f32 MFMA")
     ap.add_argument("--expanded-weights", action="store_true",
                     help="expand the u8/u16 weights at load time (fp32 / three bf16 planes in HBM) instead of keeping "
                          "them quantised in HBM with dequantisation inside the kernels (the default, BASELINE config 5)")
+    ap.add_argument("--u8-dequant", action="store_true", help="u8 weights dequantised per element (UMX_CREATE_U8_DEQUANT)")
+    ap.add_argument("--traffic-csv", default=None, help="rocprofv3 PMC summary to take roofline.traffic from "
+                                                        "(default: the newest profiles/r*_pmc_fetch_write_per_kernel.csv)")
     args = ap.parse_args()
 
     import torch
@@ -115,35 +163,37 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     pkg = ge.load_package()
-    H, N = args.hidden, args.segment_samples
+    import importlib
+    mg = importlib.import_module("umx_cpp_amd.multigpu")
+    H, N, B = args.hidden, args.segment_samples, args.tracks
     # synthetic UMX-L-shaped weights in the reference's file format (u8/u16 + scale/offset); every
     # rank writes its own copy (seeded, identical) to avoid a file-system race
     tmpdir = tempfile.mkdtemp(prefix=f"umx_bench_r{rank}_")
     wpath = os.path.join(tmpdir, "ggml-model-synth-u8.bin")
     pkg.ggml.write_model(wpath, pkg.ggml.synth_weights(H, seed=0), H, compress=False)
-    B = args.tracks
-    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=not args.expanded_weights,
-                               gemm=args.gemm, tracks=B, lstm_batched=args.batched_lstm)
-    T = eng.T
+    if args.mode == "track":
+        return bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath)
 
-    # each rank (and each track lane): its own track
-    audios = [torch.from_numpy(np.ascontiguousarray(pkg.ggml.synth_audio(N, seed=rank * 16 + b).T).ravel()).to(dev)
-              for b in range(B)]  # (2,n) interleaved, in HBM
-    audio = audios[0]
-    # two output sets: consecutive segments are in flight together (two pipeline slots) and must not share stems
-    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4 * B)] for _ in range(2)]
+    def make_engine(tracks, batched):
+        return pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=not args.expanded_weights,
+                                    gemm=args.gemm, tracks=tracks, lstm_batched=batched, u8_dequant=args.u8_dequant)
+    eng = make_engine(B, args.batched_lstm)
+    T = eng.T
     flags = (pkg.FLAG_NO_WIENER if args.no_wiener else 0) | (pkg.FLAG_LSTM_STEPWISE if args.stepwise_lstm else 0) | \
-        (pkg.FLAG_LSTM_FORCE_SAFE if args.safe_lstm else 0) | (pkg.FLAG_LSTM_PROFILE if args.lstm_profile else 0)
+        (pkg.FLAG_LSTM_FORCE_SAFE if args.safe_lstm else 0) | (pkg.FLAG_LSTM_PROFILE if args.lstm_profile else 0) | \
+        (0x700 if args.vocals_only else 0)
+
+    # each rank and each track lane: its own track; (2,n) interleaved, in HBM
+    waves = [np.ascontiguousarray(pkg.ggml.synth_audio(N, seed=rank * 16 + b).T).ravel() for b in range(B)]
+    audios = [torch.from_numpy(w).to(dev) for w in waves]
+    # two output sets: consecutive steps are in flight together (two pipeline slots) and must not share stems
+    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4 * B)] for _ in range(2)]
     ptr_sets = [[o.data_ptr() for o in st_] for st_ in out_sets]
+    aptrs = [a.data_ptr() for a in audios]
     nstep = [0]
 
-    aptrs = [a.data_ptr() for a in audios]
-
     def step():
-        if B == 1:
-            eng.infer_segment_device(audio.data_ptr(), N, ptr_sets[nstep[0] & 1], flags)
-        else:
-            eng.infer_batch_ptrs(aptrs, [N] * B, ptr_sets[nstep[0] & 1], flags)
+        eng.infer_batch_ptrs(aptrs, [N] * B, ptr_sets[nstep[0] & 1], flags)
         nstep[0] += 1
         if args.serial:
             eng.sync()
@@ -152,152 +202,267 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
 
-    import importlib
-    mg = importlib.import_module("umx_cpp_amd.multigpu")
+    dd = dist if world > 1 else None
     # W untimed warm-up steps, barrier + synchronize on both sides of exactly K steps, MAX over ranks
-    dt = mg.timed_region(step, fence, args.steps, args.warmup, dist=dist if world > 1 else None, world=world, device=dev)
-    # per-stage device time from hipEvents on the engine's own streams.  (a) the last two segments of the
-    # timed region (one per pipeline slot; consecutive segments overlap there, so a span includes the other
-    # slot's kernels -- this is the duration rocprofv3 reports for the same command); (b) three extra
-    # segments run one at a time after the timed region (the kernel alone on the chip).
+    dt = mg.timed_region(step, fence, args.steps, args.warmup, dist=dd, world=world, device=dev)
+    # per-stage device time from hipEvents on the engine's own streams.  (a) the last two steps of the timed region
+    # (one per pipeline slot; consecutive steps overlap there, so a span includes the other slot's kernels -- this is
+    # the duration rocprofv3 reports for the same command); (b) extra steps run one at a time afterwards (each kernel
+    # alone on the chip).
     prof_pipelined = eng.lstm_profile() if args.lstm_profile else None
-    st = [eng.stage_times(slot=i) for i in (0, 1)]
-    st = [d for d in st if d]
+    st = [d for d in (eng.stage_times(slot=i) for i in (0, 1)) if d]
     stage_ms = {k: sum(d[k] for d in st) / len(st) for k in st[0]} if st else {}
     serial = []
-    for _ in range(3):
+    stage_alone_ms = {}
+    for _ in range(2):
         t1 = time.perf_counter()
         step()
         eng.sync()
         serial.append((time.perf_counter() - t1) * 1e3)
         stage_alone_ms = eng.stage_times()
-    serial_ms = min(serial)
     finite = bool(all(torch.isfinite(o).all().item() for st_ in out_sets for o in st_))
+    lstm_mode, batched = eng.lstm_mode(), eng.lstm_is_batched()
+
+    # ---- value_pcie: pinned host buffers in and out, the same number of steps timed the same way
+    dt_pcie = None
+    if not args.no_pcie:
+        try:
+            h_in = [torch.from_numpy(w).pin_memory() for w in waves]
+            h_out = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4 * B)] for _ in range(2)]
+            hp_in, hp_out = [t.data_ptr() for t in h_in], [[t.data_ptr() for t in s] for s in h_out]
+            k = [0]
+
+            def step_pcie():
+                eng.infer_batch_ptrs(hp_in, [N] * B, hp_out[k[0] & 1], flags, where="host_async")
+                k[0] += 1
+            dt_pcie = mg.timed_region(step_pcie, fence, args.steps, max(2, args.warmup // 2), dist=dd, world=world, device=dev)
+            finite = finite and bool(all(torch.isfinite(o).all().item() for s in h_out for o in s))
+            del h_in, h_out
+        except Exception as e:  # noqa: BLE001 - reported, never a reason to lose the main number
+            dt_pcie = repr(e)
+    weight_bytes = eng.weight_bytes()
+    if args.lstm_profile and rank == 0:
+        for tag, pr in (("pipelined", prof_pipelined), ("alone", eng.lstm_profile())):
+            for layer in range(3):
+                for w in range(2):
+                    c = pr[layer, w]
+                    n = max(int(c[4]), 1)
+                    print(f"# lstm {tag} layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} barrier {c[2] / n:.0f} "
+                          f"gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])}) "
+                          f"[poll: sleep {c[6] / n:.0f} first-loads {c[7] / n:.0f}]", file=sys.stderr)
+    eng.close()
+    del eng, audios, out_sets
+    torch.cuda.empty_cache()
+
+    # ---- single-track engine on the same GPU (latency view), rank 0 of a 1-GPU run only
+    single = None
+    if rank == 0 and world == 1 and B > 1 and not args.no_single_track:
+        e1 = make_engine(1, False)
+        a1 = torch.from_numpy(waves[0]).to(dev)
+        o1 = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)] for _ in range(2)]
+        p1 = [[o.data_ptr() for o in s] for s in o1]
+        k1 = [0]
+
+        def step1():
+            e1.infer_segment_device(a1.data_ptr(), N, p1[k1[0] & 1], flags)
+            k1[0] += 1
+
+        def fence1():
+            e1.sync()
+            torch.cuda.synchronize()
+        d1 = mg.timed_region(step1, fence1, 16, 4)
+        s1 = [d for d in (e1.stage_times(slot=i) for i in (0, 1)) if d]
+        lstm1 = sum(sum(d[f"lstm_rec{l}"] for l in range(3)) for d in s1) / (3 * len(s1))
+        step1()
+        e1.sync()
+        alone1 = e1.stage_times()
+        single = {"value": round(16 * (N / 44100.0) / d1, 2), "unit": "x realtime", "ms_per_step": round(d1 / 16 * 1e3, 3),
+                  "tracks_per_gpu": 1, "lstm_kernel": "single-track (VALU, lstm_persistent_kernel)",
+                  "lstm_launch_ms": round(lstm1, 4), "lstm_launch_ms_alone": round(sum(alone1[f"lstm_rec{l}"] for l in range(3)) / 3, 4)}
+        e1.close()
 
     if rank == 0:
         seg_sec = N / 44100.0
         value = world * B * args.steps * seg_sec / dt
-        gemm, rec, byt = algorithmic_work(T, H, not args.no_wiener)
-        gemm = {k: v * B for k, v in gemm.items()}  # a stage's time spans every track lane
-        rec *= B
-        byt = {k: v * B for k, v in byt.items()}
-        lstm_ms = sum(stage_ms.get(f"lstm_rec{l}", 0.0) for l in range(3))
-        gemm_ms = stage_ms.get("fc1", 0) + stage_ms.get("fc2", 0) + stage_ms.get("fc3_mask", 0) + \
-            sum(stage_ms.get(f"lstm_ih{l}", 0.0) for l in range(3))
-        gemm_flops = gemm["fc1"] + 3 * gemm["lstm_ih"] + gemm["fc2"] + gemm["fc3_mask"]
-        # dominant kernel by device time
-        lstm_alone_ms = sum(stage_alone_ms.get(f"lstm_rec{l}", 0.0) for l in range(3))
-        if lstm_ms >= gemm_ms:
-            # The recurrence is neither HBM- nor MFMA-bound: it is 3*T serially dependent steps whose floor is
-            # the cross-CU hand-off latency.  The schema wants hbm|mfma, so its fp32 FMA
-            # work is priced against the f32 peak; the HBM and latency views are given next to it.
-            per_launch_flops = rec
-            per_launch_ms = lstm_ms / 3
-            ach = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
-            whh_el = 4.0 if args.expanded_weights else 1.0  # W_hh resident as fp32 or as the file's u8
-            alg_bytes = 4.0 * (4 * T * 4 * H + 8 * 2 * H + 4 * T * H) + whh_el * 8 * (H // 2) * (2 * H)  # P, b_hh, out, W_hh
-            traffic = None
-            if H == 1024 and T == 2584 and eng.lstm_mode() >= 1:
-                # profiles/r01_v5_pmc_fetch_write_per_kernel.csv (u8 W_hh) / r01_v4 (fp32 W_hh): rocprofv3 --pmc
-                # FETCH_SIZE / WRITE_SIZE (separate passes), KB per launch; FETCH_SIZE x2 on gfx950
-                # (MI355X_MICROARCH.md HBM section)
-                traffic = (2 * (99512.3 if args.expanded_weights else 86940.7) + 41456.0) * 1024
-            roofline = {"kernel": "lstm_persistent_kernel<64>" if eng.lstm_was_persistent() else "lstm_step_kernel",
-                        "bound": "mfma", "achieved": round(ach, 3), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(ach / F32_MFMA_PEAK_TF, 5), "traffic": traffic,
-                        "launch_ms": round(per_launch_ms, 4), "launch_ms_alone": round(lstm_alone_ms / 3, 4),
-                        "algorithmic_flops_per_launch": per_launch_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                        "hbm_view": {"achieved_GBs": round(alg_bytes / (per_launch_ms * 1e-3) / 1e9, 1),
-                                     "peak_GBs": HBM_PEAK_GBS,
-                                     "frac": round(alg_bytes / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                        "latency_view": {"serial_steps_per_launch": T, "us_per_step": round(per_launch_ms * 1e3 / T, 3),
-                                         "us_per_step_alone": round(lstm_alone_ms * 1e3 / (3 * T), 3),
-                                         "handoff_floor_us": 0.25}}
-        else:
-            ach = gemm_flops / (gemm_ms * 1e-3) / 1e12
-            roofline = {"kernel": "gemm_tn_kernel", "bound": "mfma", "achieved": round(ach, 3),
-                        "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TF, 5),
-                        "traffic": None}
-        gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
-        # the GEMM kernels against their own roof, stand-alone durations: fp32-equivalent (algorithmic) flops, and for
-        # the bf16x3 flavour the six bf16 products it actually issues per fp32 product, against the dense bf16 peak
-        gemm_alone_ms = stage_alone_ms.get("fc1", 0) + stage_alone_ms.get("fc2", 0) + stage_alone_ms.get("fc3_mask", 0) + \
-            sum(stage_alone_ms.get(f"lstm_ih{l}", 0.0) for l in range(3))
+        gemm, rec, byt = algorithmic_work(T, H)
         flavour = args.gemm or os.environ.get("UMX_GEMM", "bf16x3")
-        gemm_view = None
-        if gemm_alone_ms > 0:
-            alg_tf = gemm_flops / (gemm_alone_ms * 1e-3) / 1e12
-            gemm_view = {"kernel": "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel", "bound": "mfma",
-                         "ms_alone": round(gemm_alone_ms, 3), "algorithmic_TFLOPs": round(alg_tf, 1),
-                         "frac_of_f32_mfma_peak": round(alg_tf / F32_MFMA_PEAK_TF, 3)}
-            if flavour == "bf16x3":
-                gemm_view.update({"issued_bf16_TFLOPs": round(6 * alg_tf, 1), "bf16_mfma_peak": 2500.0,
-                                  "frac_of_bf16_mfma_peak": round(6 * alg_tf / 2500.0, 3)})
-        stream_ms = sum(stage_ms.get(k, 0.0) for k in ("stft", "wiener", "istft", "ola"))
-        stream_gbs = sum(byt.values()) / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else None
+        u8x = flavour == "bf16x3" and not args.expanded_weights and not args.u8_dequant  # u8 weights as exact bf16 integers
+        traffic_src = args.traffic_csv or next(iter(sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_fetch_write_per_kernel.csv")),
+                                                           reverse=True)), None)
+        traffic = read_traffic(traffic_src) if traffic_src else {}
+
+        def find_traffic(*needles):
+            for kk, v in traffic.items():
+                if all(nd in kk for nd in needles):
+                    return v
+            return None
+
+        # ---- one entry per kernel family: launches per step, live duration per launch, work per launch, roof
+        def gemm_entry(stage_keys, work_key, products, name, tneedles):
+            launches = len(stage_keys) * B
+            ms = sum(stage_ms.get(kk, 0.0) for kk in stage_keys) / launches
+            ms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in stage_keys) / launches
+            alg = gemm[work_key]
+            issued = alg * products if flavour == "bf16x3" else alg
+            peak = BF16_MFMA_PEAK_TF if flavour == "bf16x3" else F32_MFMA_PEAK_TF
+            ach = issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "mfma", "launches_per_step": launches, "launch_ms": round(ms, 4),
+                    "launch_ms_alone": round(ms_alone, 4), "algorithmic_flops_per_launch": alg,
+                    "issued_flops_per_launch": issued, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "frac_alone": round(issued / (ms_alone * 1e-3) / 1e12 / peak, 4) if ms_alone > 0 else None,
+                    "algorithmic_TFLOPs_alone": round(alg / (ms_alone * 1e-3) / 1e12, 1) if ms_alone > 0 else None,
+                    "traffic": find_traffic(*tneedles)}
+        gname = "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel"
+        p8 = 3 if u8x else 6
+        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gname}<G_FC1>", (gname, "ILi0E")),
+                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gname}<G_IH>", (gname, "ILi1E")),
+                   gemm_entry(["fc2"], "fc2", 6, f"{gname}<G_FC2>", (gname, "ILi2E")),
+                   gemm_entry(["fc3_mask"], "fc3_mask", 6, f"{gname}<G_FC3>", (gname, "ILi3E"))]
+        lstm_keys = [f"lstm_rec{l}" for l in range(3)]
+        lms = sum(stage_ms.get(kk, 0.0) for kk in lstm_keys) / 3
+        lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3
+        lstm_alg = rec * B
+        if batched:
+            lp = 3 if (not args.expanded_weights and not args.u8_dequant) else 6
+            lstm_issued = rec * 16 * lp * (1.25 if lp == 3 else 1.0)  # 16 tracks wide whatever B; + the all-ones tile of the u8 form
+            lname = "lstm_batch_kernel"
+        else:
+            lstm_issued = lstm_alg
+            lname = "lstm_persistent_kernel" if lstm_mode >= 1 else "lstm_step_kernel"
+        lach = lstm_alg / (lms * 1e-3) / 1e12 if lms > 0 else 0.0
+        kernels.append({"kernel": lname, "bound": "latency", "launches_per_step": 3, "launch_ms": round(lms, 4),
+                        "launch_ms_alone": round(lms_alone, 4), "algorithmic_flops_per_launch": lstm_alg,
+                        "issued_flops_per_launch": lstm_issued, "achieved": round(lach, 2), "peak": F32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(lach / F32_MFMA_PEAK_TF, 4),
+                        "frac_alone": round(lstm_alg / (lms_alone * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4) if lms_alone > 0 else None,
+                        "issued_bf16_frac_alone": round(lstm_issued / (lms_alone * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 4) if batched and lms_alone > 0 else None,
+                        "serial_steps_per_launch": T, "us_per_step": round(lms * 1e3 / T, 3), "us_per_step_alone": round(lms_alone * 1e3 / T, 3),
+                        "handoff_floor_us": 0.25,
+                        "frac_latency": round(0.25 / (lms_alone * 1e3 / T), 4) if lms_alone > 0 else None,
+                        "tracks_per_serial_step": B,
+                        "note": "3*T serially dependent steps per segment; priced against the fp32 roof on ALGORITHMIC flops (2*T*Hl*4Hl*8 chains*tracks), "
+                                "frac_latency = measured cross-CU hand-off floor (tools/handoff_probe.hip) / step time",
+                        "traffic": find_traffic("lstm_batch" if batched else "lstm_persistent")})
+
+        def stream_entry(key, name, nbytes, tneedle):
+            ms = stage_ms.get(key, 0.0) / B
+            ms_alone = stage_alone_ms.get(key, 0.0) / B
+            ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "hbm", "launches_per_step": B, "launch_ms": round(ms, 4), "launch_ms_alone": round(ms_alone, 4),
+                    "algorithmic_bytes_per_launch": nbytes, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "frac_alone": round(nbytes / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_alone > 0 else None,
+                    "traffic": find_traffic(tneedle)}
+        kernels += [stream_entry("stft", "stft_kernel", byt["stft"], "stft_kernel"),
+                    stream_entry("wiener", "mixphase_kernel" if args.no_wiener else "wiener_{stats,finish,apply}_kernel (3 launches)",
+                                 byt["mixphase"] if args.no_wiener else byt["wiener"], "wiener_apply"),
+                    stream_entry("istft", "istft_frames_kernel", byt["istft"], "istft_frames"),
+                    stream_entry("ola", "istft_ola_kernel", byt["ola"], "istft_ola")]
+        dominant = max(kernels, key=lambda kk: kk["launch_ms"] * kk["launches_per_step"])
+        roofline = {kk: dominant.get(kk) for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
+                                                    "launch_ms_alone", "launches_per_step", "algorithmic_flops_per_launch",
+                                                    "issued_flops_per_launch", "frac_alone") if kk in dominant}
+        if roofline.get("bound") == "latency":  # the schema's enum is hbm | mfma; the batched recurrence runs on the matrix cores
+            roofline["bound_detail"] = "latency (serial recurrence)"
+            roofline["bound"] = "mfma"
+            roofline["frac_latency"] = dominant["frac_latency"]
+        roofline["traffic_source"] = os.path.relpath(traffic_src, ROOT) if traffic_src and traffic else None
+        roofline["share_of_device_time"] = round(dominant["launch_ms"] * dominant["launches_per_step"] /
+                                                 max(sum(kk["launch_ms"] * kk["launches_per_step"] for kk in kernels), 1e-9), 3)
+        gemm_alone_ms = sum(kk["launch_ms_alone"] * kk["launches_per_step"] for kk in kernels[:4])
+        gemm_alg = sum(kk["algorithmic_flops_per_launch"] * kk["launches_per_step"] for kk in kernels[:4])
+        gemm_issued = sum(kk["issued_flops_per_launch"] * kk["launches_per_step"] for kk in kernels[:4])
         line = {
             "metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg",
             "value": round(value, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("UMX-L single 60 s segment, 4 stems" +
+            "value_pcie": (round(world * B * args.steps * seg_sec / dt_pcie, 2) if isinstance(dt_pcie, float) else None),
+            "value_pcie_note": ("same steps with pinned host buffers: H2D audio + kernels + D2H stems inside the timed region, "
+                                f"{B * 2 * N * 4 * 5 / 1e6:.0f} MB over PCIe per step" if isinstance(dt_pcie, float) else dt_pcie),
+            "ms_per_step_pcie": round(dt_pcie / args.steps * 1e3, 3) if isinstance(dt_pcie, float) else None,
+            "single_track": single,
+            "config": {"workload": ("UMX-L single 60 s segment, " + ("vocals model only" if args.vocals_only else "4 stems") +
                                     (" (no Wiener)" if args.no_wiener else " + multichannel Wiener EM") +
-                                    " on 1 MI355X per rank; seeded synthetic 44.1 kHz stereo, synthetic "
-                                    "UMX-L-shaped u8/u16 ggml weights"),
-                       "hidden": H, "segment_samples": N, "frames": T, "stems": 4,
-                       "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(
-                           eng.lstm_mode(), "?"),
-                       "gemm": ((args.gemm or os.environ.get("UMX_GEMM", "bf16x3")) +
-                                (" (fp32 operands split into 3 bf16 terms, 6 products, f32 accumulate: error below fp32 rounding)"
-                                 if (args.gemm or os.environ.get("UMX_GEMM", "bf16x3")) == "bf16x3" else " MFMA")),
+                                    f" on 1 MI355X per rank, {B} independent track(s) per GPU (one 60 s segment of each per step); "
+                                    "seeded synthetic 44.1 kHz stereo, synthetic UMX-L-shaped u8/u16 ggml weights"),
+                       "hidden": H, "segment_samples": N, "frames": T, "stems": 4, "tracks_per_gpu": B,
+                       "audio_seconds_per_step": B * seg_sec,
+                       "lstm_kernel": ("batched, matrix cores (lstm_batch_kernel)" if batched else "single-track, VALU (lstm_persistent_kernel)"),
+                       "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
+                       "gemm": (flavour + (" (fp32 activations split into 3 bf16 terms, f32 accumulate; u8 weights exact in one bf16 term "
+                                           "(3 products), u16 / fp32 weights split in three (6 products): error below fp32 rounding)"
+                                           if flavour == "bf16x3" else " MFMA")),
                        "weights_resident": ("expanded at load (f32 / bf16 planes)" if args.expanded_weights
-                                            else "u8/u16 as in the file (dequantised in the kernels)"),
-                       "weight_bytes": eng.weight_bytes(),
-                       "tracks_per_gpu": B, "lstm_kernel": "batched (matrix cores)" if eng.lstm_is_batched() else "single-track (VALU)",
-                       "sharding": f"{world} x {B} independent tracks (one 60 s segment of each per step)"},
+                                            else "u8/u16 as in the file (BASELINE config 5)"),
+                       "weight_bytes": weight_bytes,
+                       "sharding": f"{world} x {B} independent tracks"},
             "roofline": roofline,
-            "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "stages_ms_unpipelined": {k: round(v, 4) for k, v in stage_alone_ms.items()},
-            "ms_per_segment_unpipelined": round(serial_ms, 3),
-            "gemm_tflops": round(gemm_tf, 2) if gemm_tf else None,
-            "gemm_view": gemm_view,
-            "streaming_gbs": round(stream_gbs, 1) if stream_gbs else None,
+            "kernels": kernels,
+            "stages_ms": {kk: round(v, 4) for kk, v in stage_ms.items()},
+            "stages_ms_unpipelined": {kk: round(v, 4) for kk, v in stage_alone_ms.items()},
+            "ms_per_step_unpipelined": round(min(serial), 3),
+            "gemm_view": {"ms_alone_per_track": round(gemm_alone_ms / B, 3),
+                          "algorithmic_TFLOPs": round(gemm_alg / (gemm_alone_ms * 1e-3) / 1e12, 1) if gemm_alone_ms > 0 else None,
+                          "issued_bf16_TFLOPs": round(gemm_issued / (gemm_alone_ms * 1e-3) / 1e12, 1) if gemm_alone_ms > 0 else None,
+                          "frac_of_bf16_mfma_peak": round(gemm_issued / (gemm_alone_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, 3) if gemm_alone_ms > 0 else None},
             "outputs_finite": finite,
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                line["cpu_baseline"] = cpu_baseline(pkg, H, wpath, args.cpu_sample_seconds)
+                line["cpu_baseline"] = cpu_baseline(pkg, wpath, args.cpu_sample_seconds, args.cpu_sample_seconds_1t)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         if args.track_seconds > 0:
+            e1 = make_engine(1, False)
             Lt = int(args.track_seconds * 44100)
             twave = pkg.ggml.synth_audio(Lt, 99)
             ta = np.ascontiguousarray(twave.T).ravel()
             touts = [np.empty(2 * Lt, np.float32) for _ in range(4)]
-            eng.separate_interleaved(ta, Lt, touts, shift_offset=4033)  # warm-up: allocates the track buffers
-            best = min(eng.separate_interleaved(ta, Lt, touts, shift_offset=4033) for _ in range(3))
+            e1.separate_interleaved(ta, Lt, touts, shift_offset=4033)  # warm-up: allocates the track buffers
+            best = min(e1.separate_interleaved(ta, Lt, touts, shift_offset=4033) for _ in range(3))
             line["track"] = {"seconds_of_audio": args.track_seconds, "wall_ms": round(best * 1e3, 2),
                              "realtime_factor": round(args.track_seconds / best, 1),
                              "segments": -(-(Lt + 22050 - 4033) // int(0.75 * N)),
                              "includes": "pageable H2D of the track, all segments pipelined, overlap-add on device, D2H of 4 stems"}
+            e1.close()
         print(json.dumps(line), flush=True)
-        if args.lstm_profile:
-            pr = eng.lstm_profile()
-            if prof_pipelined is not None and not args.serial:
-                pp = prof_pipelined.reshape(-1)[:48].reshape(3, 2, 8)
-                for layer in range(3):
-                    for w in range(2):
-                        c = pp[layer, w]
-                        n = max(int(c[4]), 1)
-                        print(f"# pipelined lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
-                              f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])})", file=sys.stderr)
-            for layer in range(3):
-                for w in range(2):
-                    c = pr[layer, w]
-                    n = max(int(c[4]), 1)
-                    print(f"# lstm layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} "
-                          f"barrier {c[2] / n:.0f} gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])})"
-                          f" [poll: sleep {c[6] / n:.0f} first-loads {c[7] / n:.0f}]", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
+    """BASELINE config 4: ONE 600 s track, its 14 segments round-robin over the ranks with the exact per-layer (h, c)
+    hand-off (multigpu.separate_track_carry_mode), weighted stems gathered on rank 0.  A step = the whole track."""
+    import torch
+    N = args.segment_samples
+    eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank)
+    secs = args.track_seconds or 600.0
+    L = int(secs * 44100)
+    wave = pkg.ggml.synth_audio(L, 99)
+    backend = mg.EnginePhases(eng)
+    dd = dist if world > 1 else None
+    res = [None]
+
+    def step():
+        res[0] = mg.separate_track_carry_mode(backend, wave, N, dist=dd, rank=rank, world=world, device=dev)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+    steps, warmup = max(1, min(args.steps, 4)), max(1, min(args.warmup, 1))
+    dt = mg.timed_region(step, fence, steps, warmup, dist=dd, world=world, device=dev)
+    if rank == 0:
+        line = {"metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg", "value": round(steps * secs / dt, 2),
+                "unit": "x realtime", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"UMX-L full-track segmented inference: one {secs:g} s track, {-(-L // int(0.75 * N))} segments "
+                                       f"round-robin over {world} MI355X, exact LSTM state carry (per-layer (h, c) point to point), "
+                                       "overlap-add gather on rank 0; host buffers in and out (BASELINE config 4)",
+                           "hidden": args.hidden, "segment_samples": N, "parallelism": f"segments over {world} ranks, carry mode"},
+                "outputs_finite": bool(all(np.isfinite(r).all() for r in res[0]))}
+        print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:
         dist.barrier()

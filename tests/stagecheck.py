@@ -46,6 +46,7 @@ def stage_report(hidden=128, n_buf=16 * 1024, n=None, flags=0, seed=5, segments=
                 continue
             r[f"fc1[{t}]"] = rel(eng.tap("fc1", t), taps["fc1_out"][t])
             r[f"lstm[{t}]"] = rel(eng.tap("lstm", t), taps["lstm_out"][t])
+            r[f"fc2[{t}]"] = rel(eng.tap("fc2", t), taps["fc2_out"][t])
             r[f"mask[{t}]"] = rel(eng.tap("mask", t), taps["mask"][t])
             r[f"target_mag[{t}]"] = rel(eng.tap("target_mag", t), taps["target_mag"][t])
         for t in range(4):

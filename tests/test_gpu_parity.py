@@ -28,7 +28,7 @@ TOL_STAGE, TOL_Y, TOL_WAVE, MIN_SDR = 2e-5, 2e-4, 1e-4, 80.0
 def _check_report(rep):
     for seg, r in rep.items():
         for k, v in r.items():
-            if k.startswith(("spec", "mix_mag", "x", "fc1", "lstm[", "mask", "target_mag", "state")):
+            if k.startswith(("spec", "mix_mag", "x", "fc1", "lstm[", "fc2", "mask", "target_mag", "state")):
                 assert v < TOL_STAGE, (seg, k, v)
             elif k.startswith("y["):
                 assert v < TOL_Y, (seg, k, v)
@@ -267,6 +267,28 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     qr.close()
 
 
+def test_mixed_weight_dtypes_across_targets(pkg, po, model_small):
+    """A GEMM launch covers the four targets with one kernel instantiation, so a matrix may stay quantised only if
+    EVERY target hands it over quantised: here target 1 brings fp32 views of fc1 / fc3 / one W_ih while the others
+    bring the file's u8 / u16 -- the engine must expand those matrices for all targets (not read u8 bytes as bf16
+    planes) and still sit on the oracle."""
+    path, om, targets = model_small
+    N = 16 * 1024
+    mixed = [dict(t) for t in targets]
+    for name in ("fc1.weight", "fc3.weight", "lstm.weight_ih_l1_reverse", "lstm.weight_hh_l2"):
+        mixed[1][name] = np.ascontiguousarray(mixed[1][name]["f32"])
+    eng = pkg.Engine(mixed, 128, N)
+    full = pkg.Engine(targets, 128, N)
+    assert eng.weight_bytes() > full.weight_bytes()
+    wave = pkg.ggml.synth_audio(N, 430)
+    got = eng.infer_segment(wave)
+    ref, _ = po.umx_inference(om, wave)
+    for t in range(4):
+        assert np.abs(got[t] - ref[t]).max() < TOL_WAVE
+    eng.close()
+    full.close()
+
+
 def test_device_resident_track_equals_host_split_and_shift(pkg, small):
     """umx_hip_split_inference / umx_hip_shift_inference (track in HBM, pipelined segments, overlap-add on
     the device) against the C++ host drivers of umx_host.h calling umx_hip_infer_segment per segment:
@@ -468,24 +490,43 @@ def test_flags_no_wiener_and_skip_targets(pkg, po, small):
     assert np.abs(got[0]).max() < 1e-6 and np.abs(got[3]).max() > 1e-3
 
 
-def test_stft_istft_roundtrip_property_on_device(pkg, small):
-    """Size-independent property from the reference's own tests (test_dsp.cpp:41-114): with an
-    all-pass network the path is STFT -> iSTFT and must return the input within 1e-4.  The engine
-    has no pass-through switch, so use the taps: spec from the device, oracle-free check that the
-    4 Wiener stems sum back to the mix within 0.5 % and that the STFT taps obey
-    Parseval-style energy consistency with the input."""
+def test_stft_istft_roundtrip_on_device_with_an_identity_mask_model(pkg):
+    """The reference's round-trip property (test_dsp.cpp:41-114: STFT -> iSTFT returns the input within 1e-4) through
+    the whole engine: a model whose mask is exactly 1 (fc3 = 0, bn3 mean = bias = 0, output_mean = 1, so
+    relu(0 * scale + 1) = 1, inference.cpp:143-166) with the Wiener step off (y = mask |X| e^{i arg X} = X,
+    wiener.cpp:96-109) makes every stem the device's iSTFT(STFT(input)).  Size-independent: also at the production
+    segment length."""
+    H = 128
+    W = pkg.ggml.synth_weights(H, seed=61)
+    for t in W:
+        t["fc3.weight"] = np.zeros_like(t["fc3.weight"])
+        t["bn3.running_mean"] = np.zeros_like(t["bn3.running_mean"])
+        t["bn3.bias"] = np.zeros_like(t["bn3.bias"])
+        t["output_mean"] = np.ones_like(t["output_mean"])
+    for N, n in ((16 * 1024, 16 * 1024), (16 * 1024, 9000), (pkg.SEGMENT_SAMPLES, pkg.SEGMENT_SAMPLES)):
+        eng = pkg.Engine(W, H, N, quantised=False)
+        wave = pkg.ggml.synth_audio(n, 51)
+        got = eng.infer_segment(wave, pkg.FLAG_NO_WIENER | pkg.FLAG_DEBUG_TAPS)
+        assert np.abs(eng.tap("mask", 2) - 1.0).max() == 0.0
+        for t in range(4):
+            assert np.abs(got[t] - wave).max() < 1e-4, (N, n, t)  # test_dsp.cpp:7 NEAR_TOLERANCE
+        # taps: |spec| is the mix magnitude, x is its 1487-bin crop stacked L|R (inference.cpp:29,52-68)
+        spec, mag, x = eng.tap("spec"), eng.tap("mix_mag"), eng.tap("x")
+        assert np.abs(np.abs(spec) - mag).max() < 1e-6 * max(mag.max(), 1.0)
+        assert (x[:, :1487] == mag[0, :, :1487]).all() and (x[:, 1487:2974] == mag[1, :, :1487]).all()
+        assert (x[:, 2974:] == 0).all()
+        eng.close()
+
+
+def test_wiener_stems_sum_back_to_the_mix(pkg, small):
+    """With the Wiener step on, the four estimates sum back to the mixture -- approximately: the gains G_j =
+    v_j R_j Cxx^-1 sum to I - 4 sqrt(eps) Cxx^-1 (F6), and the (Re+Im)^2 PSD of F5 applies to the update, not to this
+    identity.  SURVEY 8c item 2 measured 0.2 % on random data; with the random (untrained) masks here 2 % is asserted."""
     eng, _, N = small
     wave = pkg.ggml.synth_audio(N, 51)
     eng.stream_reset()
     got = eng.infer_segment(wave)
-    mix_err = np.abs(sum(got) - wave).max() / np.abs(wave).max()
-    assert mix_err < 0.05
-    spec = eng.tap("spec")
-    mag = eng.tap("mix_mag")
-    assert np.abs(np.abs(spec) - mag).max() < 1e-3 * mag.max()
-    x = eng.tap("x")
-    assert (x[:, :1487] == mag[0, :, :1487]).all() and (x[:, 1487:2974] == mag[1, :, :1487]).all()
-    assert (x[:, 2974:] == 0).all()
+    assert np.abs(sum(got) - wave).max() / np.abs(wave).max() < 2e-2
 
 
 def test_full_size_segment_vs_oracle():
@@ -494,6 +535,22 @@ def test_full_size_segment_vs_oracle():
     on the GPU box's 256 cores); every stage is compared, then SDR of HIP vs oracle."""
     rep = stagecheck.stage_report(1024, 2_646_000, segments=2, verbose=False)
     assert rep[0]["persistent"] is True
+    _check_report(rep)
+
+
+def test_full_size_config2_no_wiener_vs_oracle():
+    """BASELINE config 2 at full size (hidden 1024, T = 2584): 4 stems, mixture phase instead of the Wiener EM."""
+    rep = stagecheck.stage_report(1024, 2_646_000, flags=0x1, segments=1, verbose=False)
+    assert rep[0]["persistent"] is True
+    _check_report(rep)
+
+
+def test_full_size_config1_vocals_only_vs_oracle():
+    """BASELINE config 1 at full size: the vocals model only (targets 0-2 skipped: their magnitudes are zero), one
+    60 s segment, against the oracle run the same way."""
+    rep = stagecheck.stage_report(1024, 2_646_000, flags=0x700, segments=1, verbose=False)
+    assert rep[0]["persistent"] is True
+    assert "lstm[3]" in rep[0] and "lstm[0]" not in rep[0]
     _check_report(rep)
 
 

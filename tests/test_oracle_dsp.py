@@ -44,6 +44,75 @@ def test_wav_rejects_other_rate(pkg, tmp_path):  # dsp.cpp:27-33 (exit(1) there;
         raise AssertionError("48 kHz file was accepted")
 
 
+def _wav_bytes(samples, channels, bits, fmt_tag, extensible=False, extra_chunk=False):
+    """A RIFF/WAVE file built by hand: samples (n, channels) ints (PCM) or floats (tag 3), little endian."""
+    import struct
+    bps = bits // 8
+    if fmt_tag == 3:
+        body = np.asarray(samples, "<f4").tobytes()
+    elif bits == 24:
+        a = np.asarray(samples, np.int64).ravel()
+        body = b"".join(int(v & 0xFFFFFF).to_bytes(3, "little") for v in a)
+    else:
+        body = np.asarray(samples, {16: "<i2", 32: "<i4"}[bits]).tobytes()
+    if extensible:  # WAVE_FORMAT_EXTENSIBLE: tag 0xFFFE, the real tag is the first word of the sub-format GUID
+        fmt = struct.pack("<HHIIHH", 0xFFFE, channels, 44100, 44100 * bps * channels, bps * channels, bits)
+        fmt += struct.pack("<HHI", 22, bits, 3 if channels == 2 else 4)
+        fmt += struct.pack("<H", fmt_tag) + bytes.fromhex("000000001000800000AA00389B71")
+    else:
+        fmt = struct.pack("<HHIIHH", fmt_tag, channels, 44100, 44100 * bps * channels, bps * channels, bits)
+    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if extra_chunk:  # an odd-sized chunk the reader must skip (with its pad byte)
+        chunks += b"LIST" + struct.pack("<I", 5) + b"hello" + b"\0"
+    chunks += b"data" + struct.pack("<I", len(body)) + body
+    return b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks
+
+
+def test_wav_reader_encodings(pkg, tmp_path):
+    """libnyquist (dsp.cpp:23-25) decodes more than 16-bit PCM.  PCM 16 / 24 / 32, 32-bit float, and the
+    same inside WAVE_FORMAT_EXTENSIBLE, mono and stereo, built by hand here: every decoder must return the same
+    waveform within its own quantisation step; integer full scale maps to 1.0 (16-bit: / 32767, the value the shipped
+    glockenspiel files decode to under the reference's first-and-last-sample test; 24 / 32-bit: / 2^23, / 2^31)."""
+    rng = np.random.default_rng(12)
+    n = 3000
+    x = rng.uniform(-0.9, 0.9, (n, 2))
+    cases = []
+    for ch in (1, 2):
+        xs = x[:, :ch]
+        cases += [(np.round(xs * 32767), ch, 16, 1, False, 1 / 32767, 1 / 32767),
+                  (np.round(xs * 8388607), ch, 24, 1, False, 1 / 8388608, 1 / 8388608),
+                  (np.round(xs * 2147483647), ch, 32, 1, False, 1 / 2147483648, 1e-7),
+                  (xs, ch, 32, 3, False, 1.0, 1e-7),
+                  (np.round(xs * 8388607), ch, 24, 1, True, 1 / 8388608, 1 / 8388608),
+                  (xs, ch, 32, 3, True, 1.0, 1e-7)]
+    for i, (smp, ch, bits, tag, ext, scale, tol) in enumerate(cases):
+        f = tmp_path / f"c{i}.wav"
+        f.write_bytes(_wav_bytes(smp, ch, bits, tag, ext, extra_chunk=(i % 2 == 1)))
+        w, nch = pkg.wav_load(f)
+        assert nch == ch and w.shape == (2, n), (i, w.shape)
+        want = x[:, :ch] if tag == 3 else smp * scale
+        assert np.abs(w[0] - want[:, 0]).max() <= tol * 1.01, (i, bits, tag, ext)
+        assert np.abs(w[1] - want[:, ch - 1]).max() <= tol * 1.01  # mono is duplicated (dsp.cpp:52-60)
+        assert np.abs(w[0] - x[:, 0]).max() < 2 * max(tol, 1e-7) + 1e-7
+    # extremes of every integer format
+    for bits, lo, hi, div in ((16, -32768, 32767, 32767.0), (24, -8388608, 8388607, 8388608.0), (32, -2147483648, 2147483647, 2147483648.0)):
+        f = tmp_path / f"ext{bits}.wav"
+        f.write_bytes(_wav_bytes(np.array([[lo, hi], [0, -1]]), 2, bits, 1))
+        w, _ = pkg.wav_load(f)
+        assert np.allclose(w[:, 0], [lo / div, hi / div], atol=1e-7) and w[0, 1] == 0
+    # refused, not misread: 8-bit PCM, 64-bit float, 3 channels
+    import pytest
+    for smp, ch, bits, tag in ((np.zeros((4, 2)), 2, 8, 1), (np.zeros((4, 2)), 2, 64, 3), (np.zeros((4, 3)), 3, 16, 1)):
+        f = tmp_path / "bad.wav"
+        body = np.zeros(4 * ch * (bits // 8), np.uint8).tobytes()
+        import struct
+        fmt = struct.pack("<HHIIHH", tag, ch, 44100, 44100 * (bits // 8) * ch, (bits // 8) * ch, bits)
+        f.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(body)) + b"WAVEfmt " + struct.pack("<I", 16) + fmt + b"data" +
+                      struct.pack("<I", len(body)) + body)
+        with pytest.raises(pkg.HostError):
+            pkg.wav_load(f)
+
+
 def test_stft_roundtrip_rand_waveform(po):  # test_dsp.cpp:41-80
     rng = np.random.default_rng(0)
     audio = rng.uniform(0, 1, (2, 4096)).astype(np.float32)

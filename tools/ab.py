@@ -15,7 +15,7 @@ for v in variants:
         if v != "default":
             env["UMX_HIP_LIB"] = os.path.abspath(v)
         tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "")
-        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--lstm-profile"] + extra
+        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--lstm-profile", "--no-pcie", "--no-single-track"] + extra
         if b == 1:
             cmd.append("--batched-lstm")
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -29,8 +29,8 @@ for v in variants:
         al = j["stages_ms_unpipelined"]
         lstm = sum(al[f"lstm_rec{l}"] for l in range(3)) / 3
         gemm = al["fc1"] + al["fc2"] + al["fc3_mask"] + sum(al[f"lstm_ih{l}"] for l in range(3))
-        prof = [ln for ln in p.stderr.splitlines() if ln.startswith("# lstm layer 1 wave")]
+        prof = [ln for ln in p.stderr.splitlines() if ln.startswith("# lstm alone layer 1 wave")]
         print(f"{tag:12s} B={b:2d} {j['ms_per_step']:8.3f} ms/step {j['value']:9.1f}x  alone: lstm/launch {lstm:7.3f} ms "
-              f"({lstm * 1e3 / j['config']['frames']:.3f} us/step) gemm {gemm:7.3f} serial {j['ms_per_segment_unpipelined']:8.3f}", flush=True)
+              f"({lstm * 1e3 / j['config']['frames']:.3f} us/step) gemm {gemm:7.3f} serial {j['ms_per_step_unpipelined']:8.3f}", flush=True)
         for ln in prof:
             print("      ", ln[2:], flush=True)

@@ -377,6 +377,15 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     auto is_q = [&](const umx_tensor_view *tv, int dtype, size_t expect) {
         return keepq && tv && tv->dtype == dtype && nelems(tv) == expect;
     };
+    // A GEMM launch covers all four targets with ONE kernel instantiation (its B-operand type is a template
+    // parameter), so a matrix stays quantised only if it is stored that way for EVERY target; otherwise it is expanded
+    // for all of them.
+    auto all_q = [&](const std::string &name, int dtype, size_t expect) {
+        for (int tg = 0; tg < 4; ++tg)
+            if (!is_q(view(tg, name), dtype, expect))
+                return false;
+        return true;
+    };
 
     gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // bf16x3 is the default (gemm_bf16x3.h)
     const bool bx = gemm_bf16x3;
@@ -447,7 +456,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         if (int rc = upload(&b.out_mean, w))
             return rc;
         // fc1 (H x 2974) -> (H x KX), zero K padding
-        if (const umx_tensor_view *tv = view(tg, "fc1.weight"); is_q(tv, UMX_DTYPE_U8, (size_t)H * NIN))
+        if (const umx_tensor_view *tv = view(tg, "fc1.weight"); all_q("fc1.weight", UMX_DTYPE_U8, (size_t)H * NIN))
         {
             if (int rc = upload_q(&b.fc1_q.q, tv, H, NIN, H, KX, nullptr, 0, H))
                 return rc;
@@ -483,7 +492,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload(&b.bn3[k], w))
                 return rc;
         }
-        if (const umx_tensor_view *tv = view(tg, "fc2.weight"); is_q(tv, UMX_DTYPE_U16, (size_t)H * 2 * H))
+        if (const umx_tensor_view *tv = view(tg, "fc2.weight"); all_q("fc2.weight", UMX_DTYPE_U16, (size_t)H * 2 * H))
         {
             if (int rc = upload_q(&b.fc2_q.q, tv, H, 2 * H, H, 2 * H, nullptr, 0, H))
                 return rc;
@@ -498,7 +507,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload_matrix(&b.fc2_w, &b.fc2_bx, v))
                 return rc;
         }
-        if (const umx_tensor_view *tv = view(tg, "fc3.weight"); is_q(tv, UMX_DTYPE_U16, (size_t)NOUT * H))
+        if (const umx_tensor_view *tv = view(tg, "fc3.weight"); all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
         {
             if (int rc = upload_q(&b.fc3_q.q, tv, NOUT, H, NOUT_PAD, H, nullptr, 0, NOUT_PAD))
                 return rc;
@@ -520,7 +529,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         {
             const umx_tensor_view *ihv[2] = {view(tg, "lstm.weight_ih_l" + std::to_string(l)),
                                              view(tg, "lstm.weight_ih_l" + std::to_string(l) + "_reverse")};
-            const bool ih_q = is_q(ihv[0], UMX_DTYPE_U8, (size_t)G * H) && is_q(ihv[1], UMX_DTYPE_U8, (size_t)G * H);
+            const bool ih_q = all_q("lstm.weight_ih_l" + std::to_string(l), UMX_DTYPE_U8, (size_t)G * H) &&
+                              all_q("lstm.weight_ih_l" + std::to_string(l) + "_reverse", UMX_DTYPE_U8, (size_t)G * H);
             std::vector<float> ihw(ih_q ? 0 : (size_t)2 * G * H), ihb((size_t)2 * G);
             for (int dir = 0; dir < 2; ++dir)
             {
