@@ -225,8 +225,7 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     ref = pkg.Engine(targets, 128, N, quantised_resident=False)
     qr = pkg.Engine(targets, 128, N, u8_dequant=True)
     qx = pkg.Engine(targets, 128, N)  # the default
-    assert qr.weight_bytes() * 3.5 < ref.weight_bytes()  # u8/u16 against three bf16 planes (+ fp32 W_hh)
-    assert qx.weight_bytes() == qr.weight_bytes()
+    assert qx.weight_bytes() * 1.8 < ref.weight_bytes()  # exact integer planes (1 or 2 per matrix) + u8 W_hh against 3 planes + fp32 W_hh
     for flags in (0, pkg.FLAG_LSTM_STEPWISE):
         ref.stream_reset()
         qr.stream_reset()
@@ -248,7 +247,10 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     p = str(tmp_path / "m.bin")
     pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=31), H, compress=False)
     ref, qr = pkg.Engine.from_file(p, N, quantised_resident=False), pkg.Engine.from_file(p, N, u8_dequant=True)
-    assert 130e6 < qr.weight_bytes() < 150e6 and 600e6 < ref.weight_bytes() < 640e6
+    assert 600e6 < ref.weight_bytes() < 640e6
+    staged = pkg.Engine.from_file(p, N, gemm="bf16x3")  # round 1's kernels keep the file's u8 / u16 bytes in HBM
+    assert 130e6 < staged.weight_bytes() < 150e6
+    staged.close()
     f32 = pkg.Engine.from_file(p, N, gemm="f32", quantised_resident=False)
     assert 440e6 < f32.weight_bytes() < 470e6
     f32q = pkg.Engine.from_file(p, N, gemm="f32")

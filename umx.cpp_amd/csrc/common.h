@@ -15,7 +15,7 @@ constexpr int CROP = 1487;  // inference.cpp:55
 constexpr int NIN = 2974;   // inference.cpp:41
 constexpr int KX = 2976;    // NIN padded to a multiple of 32 (GEMM K tile)
 constexpr int NOUT = 4098;  // inference.cpp:53
-constexpr int NOUT_PAD = 4224; // NOUT padded to a multiple of 128 (GEMM N tile)
+constexpr int NOUT_PAD = 4352; // NOUT padded to a multiple of 256 (largest GEMM N tile)
 constexpr int WIENER_BATCH = 200; // wiener.hpp:16
 constexpr float WIENER_EPS = 1e-10f;  // wiener.hpp:12
 constexpr float WIENER_SCALE = 10.0f; // wiener.hpp:13

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "gemm_kernels.h"
 #include "gemm_bf16x3.h"
+#include "gemm_planes.h"
 #include "lstm_kernels.h"
 #include "lstm_batch.h"
 #include "track_kernels.h"
@@ -44,8 +45,18 @@ struct QMat
     float s[2] = {1.f, 1.f}, o[2] = {0.f, 0.f};
 };
 
+// A GEMM weight as exact bf16 planes [nbp][N][K] (gemm_planes.h): u8 -> 1 plane of q - 128, u16 -> 2 planes
+// 256 (qh - 128), ql - 128, fp32 -> 3 split terms; (scale, offset + c scale) per file tensor (W_ih: two).
+struct PMat
+{
+    unsigned short *p = nullptr;
+    int nbp = 3;
+    float s[2] = {1.f, 1.f}, o2[2] = {0.f, 0.f};
+};
+
 struct TargetBufs // weights of one target (shared by both pipeline slots)
 {
+    PMat fc1_p, ih_p[3], fc2_p, fc3_p; // gemm_planes.h (the default GEMM flavour)
     QMat fc1_q, ih_q[3], fc2_q, fc3_q; // used instead of the fp32 matrix when .q != nullptr
     unsigned short *fc1_bx = nullptr, *ih_bx[3] = {}, *fc2_bx = nullptr, *fc3_bx = nullptr; // bf16 planes [3][N][K] (gemm_bf16x3.h)
     float *fc1_w = nullptr, *in_scale = nullptr, *in_mean = nullptr, *bn1[4] = {};
@@ -58,6 +69,9 @@ struct TargetAct // activations of one target in one pipeline slot
 {
     float *cat = nullptr, *la = nullptr, *lb = nullptr, *P = nullptr, *a2 = nullptr, *mag = nullptr,
           *mask_dbg = nullptr;
+    // gemm_planes.h: every GEMM's A operand split once into three bf16 planes, and its row sums
+    unsigned short *xs_p = nullptr, *cat_p = nullptr, *la_p = nullptr, *lb_p = nullptr, *a2_p = nullptr;
+    float *rs_xs = nullptr, *rs_catL = nullptr, *rs_catR = nullptr, *rs_la = nullptr, *rs_lb = nullptr, *rs_a2 = nullptr;
 };
 
 enum
@@ -77,6 +91,7 @@ enum
     ST_OLA,
     ST_COUNT
 };
+enum { SP_XS = 0, SP_CATL, SP_LA, SP_LB, SP_CATR, SP_A2 }; // which A operand launch_split prepares
 const char *kStageNames[ST_COUNT] = {"stft",  "fc1", "lstm_ih0", "lstm_rec0", "lstm_ih1", "lstm_rec1", "lstm_ih2",
                                      "lstm_rec2", "fc2", "fc3_mask", "wiener",  "istft",    "ola"};
 
@@ -199,6 +214,12 @@ struct umx_hip_ctx
              unsigned create_flags, int n_tracks);
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
     bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
+    bool gemm_planes = false;     // ... with both operands pre-split / re-encoded as bf16 planes and LDS-DMA staging (gemm_planes.h)
+    void launch_split(Lane &ln, int nl, hipStream_t st, int which, const int *active, int nact);
+    void launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
+    // one GEMM stage for the track lanes with audio: the plane GEMMs take every run of consecutive lanes in one launch
+    void launch_gemm_lanes(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, int mode, int layer, const int *active,
+                           int nact, bool dbg);
     bool u8_dequant = false;      // UMX_CREATE_U8_DEQUANT: u8 weights dequantised per element (model.cpp:610-616) before they
                                   // are multiplied, instead of exact bf16 integers with the affine map applied to the sum
     unsigned char *whh_q[3] = {}; // u8-resident W_hh (create flag), same layout as whh[]
@@ -308,7 +329,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     S = Hl / LSTM_UNITS_PER_WG;
     N = segment_samples;
     T = N / HOP + 1; // dsp.hpp:48
-    Tp = round_up(T, GEMM_BM);
+    Tp = round_up(T, 256); // multiple of the largest GEMM M tile: a tile never straddles two track lanes
     nbatch = (T + WIENER_BATCH - 1) / WIENER_BATCH;
 
     // ---- index the tensor views by (target, name)
@@ -387,8 +408,40 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         return true;
     };
 
-    gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // bf16x3 is the default (gemm_bf16x3.h)
+    gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // the bf16 matrix cores are the default
+    gemm_planes = gemm_bf16x3 && !(create_flags & UMX_CREATE_GEMM_STAGED); // gemm_planes.h unless gemm_bf16x3.h is asked for
     const bool bx = gemm_bf16x3;
+    // A GEMM weight as exact bf16 planes (PMat): (rows x cols) of `tv` (u8 / u16 as stored) or of `f32`, source row
+    // rowmap[r] -> destination row dst_row0 + r of a [nbp][total_rows][cols_pad] matrix built in `host`
+    auto fill_planes = [&](std::vector<unsigned short> &host, int nbp, size_t total_rows, int cols_pad, const umx_tensor_view *tv,
+                           const float *f32, int rows, int cols, const std::vector<int> *rowmap, size_t dst_row0) {
+        const size_t plane = total_rows * (size_t)cols_pad;
+        if (host.empty())
+            host.assign((size_t)nbp * plane, 0);
+        for (int r = 0; r < rows; ++r)
+        {
+            const int sr = rowmap ? (*rowmap)[r] : r;
+            unsigned short *d = &host[(dst_row0 + r) * cols_pad];
+            for (int k = 0; k < cols; ++k)
+            {
+                if (nbp == 1)
+                    d[k] = bf16_rne_bits((float)static_cast<const uint8_t *>(tv->data)[(size_t)sr * cols + k] - 128.0f);
+                else if (nbp == 2)
+                {
+                    const unsigned q = static_cast<const uint16_t *>(tv->data)[(size_t)sr * cols + k];
+                    d[k] = bf16_rne_bits(256.0f * ((float)(q >> 8) - 128.0f));
+                    d[plane + k] = bf16_rne_bits((float)(q & 255u) - 128.0f);
+                }
+                else
+                    split3_host(f32[(size_t)sr * cols + k], d[k], d[plane + k], d[2 * plane + k]);
+            }
+        }
+    };
+    auto upload_pmat = [&](PMat &pm, std::vector<unsigned short> &host, int nbp) -> int {
+        pm.nbp = nbp;
+        weight_bytes += host.size() * sizeof(unsigned short);
+        return upload(&pm.p, host);
+    };
     // fp32 matrix (kernel layout, padded) -> device; as three bf16 planes when the bf16x3 GEMMs are selected
     auto upload_matrix = [&](float **dst_f32, unsigned short **dst_bx, const std::vector<float> &w) -> int {
         if (!bx)
@@ -456,7 +509,29 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         if (int rc = upload(&b.out_mean, w))
             return rc;
         // fc1 (H x 2974) -> (H x KX), zero K padding
-        if (const umx_tensor_view *tv = view(tg, "fc1.weight"); all_q("fc1.weight", UMX_DTYPE_U8, (size_t)H * NIN))
+        const bool exact_ok = keepq && !(create_flags & UMX_CREATE_U8_DEQUANT); // integers as exact bf16 planes
+        if (gemm_planes)
+        {
+            std::vector<unsigned short> host;
+            const umx_tensor_view *tv = view(tg, "fc1.weight");
+            if (exact_ok && all_q("fc1.weight", UMX_DTYPE_U8, (size_t)H * NIN))
+            {
+                fill_planes(host, 1, H, KX, tv, nullptr, H, NIN, nullptr, 0);
+                b.fc1_p.s[0] = tv->scale;
+                b.fc1_p.o2[0] = tv->offset + 128.0f * tv->scale;
+                if (int rc = upload_pmat(b.fc1_p, host, 1))
+                    return rc;
+            }
+            else
+            {
+                if (!get(tg, "fc1.weight", (size_t)H * NIN, v))
+                    return UMX_ERR_MODEL;
+                fill_planes(host, 3, H, KX, nullptr, v.data(), H, NIN, nullptr, 0);
+                if (int rc = upload_pmat(b.fc1_p, host, 3))
+                    return rc;
+            }
+        }
+        else if (const umx_tensor_view *tv = view(tg, "fc1.weight"); all_q("fc1.weight", UMX_DTYPE_U8, (size_t)H * NIN))
         {
             if (int rc = upload_q(&b.fc1_q.q, tv, H, NIN, H, KX, nullptr, 0, H))
                 return rc;
@@ -492,7 +567,28 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload(&b.bn3[k], w))
                 return rc;
         }
-        if (const umx_tensor_view *tv = view(tg, "fc2.weight"); all_q("fc2.weight", UMX_DTYPE_U16, (size_t)H * 2 * H))
+        if (gemm_planes)
+        {
+            std::vector<unsigned short> host;
+            const umx_tensor_view *tv = view(tg, "fc2.weight");
+            if (exact_ok && all_q("fc2.weight", UMX_DTYPE_U16, (size_t)H * 2 * H))
+            {
+                fill_planes(host, 2, H, 2 * H, tv, nullptr, H, 2 * H, nullptr, 0);
+                b.fc2_p.s[0] = tv->scale;
+                b.fc2_p.o2[0] = tv->offset + 32896.0f * tv->scale;
+                if (int rc = upload_pmat(b.fc2_p, host, 2))
+                    return rc;
+            }
+            else
+            {
+                if (!get(tg, "fc2.weight", (size_t)H * 2 * H, v))
+                    return UMX_ERR_MODEL;
+                fill_planes(host, 3, H, 2 * H, nullptr, v.data(), H, 2 * H, nullptr, 0);
+                if (int rc = upload_pmat(b.fc2_p, host, 3))
+                    return rc;
+            }
+        }
+        else if (const umx_tensor_view *tv = view(tg, "fc2.weight"); all_q("fc2.weight", UMX_DTYPE_U16, (size_t)H * 2 * H))
         {
             if (int rc = upload_q(&b.fc2_q.q, tv, H, 2 * H, H, 2 * H, nullptr, 0, H))
                 return rc;
@@ -507,7 +603,28 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload_matrix(&b.fc2_w, &b.fc2_bx, v))
                 return rc;
         }
-        if (const umx_tensor_view *tv = view(tg, "fc3.weight"); all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
+        if (gemm_planes)
+        {
+            std::vector<unsigned short> host;
+            const umx_tensor_view *tv = view(tg, "fc3.weight");
+            if (exact_ok && all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
+            {
+                fill_planes(host, 2, NOUT_PAD, H, tv, nullptr, NOUT, H, nullptr, 0);
+                b.fc3_p.s[0] = tv->scale;
+                b.fc3_p.o2[0] = tv->offset + 32896.0f * tv->scale;
+                if (int rc = upload_pmat(b.fc3_p, host, 2))
+                    return rc;
+            }
+            else
+            {
+                if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
+                    return UMX_ERR_MODEL;
+                fill_planes(host, 3, NOUT_PAD, H, nullptr, v.data(), NOUT, H, nullptr, 0);
+                if (int rc = upload_pmat(b.fc3_p, host, 3))
+                    return rc;
+            }
+        }
+        else if (const umx_tensor_view *tv = view(tg, "fc3.weight"); all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
         {
             if (int rc = upload_q(&b.fc3_q.q, tv, NOUT, H, NOUT_PAD, H, nullptr, 0, NOUT_PAD))
                 return rc;
@@ -529,9 +646,12 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         {
             const umx_tensor_view *ihv[2] = {view(tg, "lstm.weight_ih_l" + std::to_string(l)),
                                              view(tg, "lstm.weight_ih_l" + std::to_string(l) + "_reverse")};
-            const bool ih_q = all_q("lstm.weight_ih_l" + std::to_string(l), UMX_DTYPE_U8, (size_t)G * H) &&
-                              all_q("lstm.weight_ih_l" + std::to_string(l) + "_reverse", UMX_DTYPE_U8, (size_t)G * H);
-            std::vector<float> ihw(ih_q ? 0 : (size_t)2 * G * H), ihb((size_t)2 * G);
+            const bool ih_q8 = all_q("lstm.weight_ih_l" + std::to_string(l), UMX_DTYPE_U8, (size_t)G * H) &&
+                               all_q("lstm.weight_ih_l" + std::to_string(l) + "_reverse", UMX_DTYPE_U8, (size_t)G * H);
+            const bool ih_exact = gemm_planes && exact_ok && ih_q8;
+            const bool ih_q = ih_q8 && (!gemm_planes || ih_exact); // the source stays u8 (no fp32 copy needed)
+            std::vector<unsigned short> ih_planes;
+            std::vector<float> ihw((ih_q || gemm_planes) ? 0 : (size_t)2 * G * H), ihb((size_t)2 * G);
             for (int dir = 0; dir < 2; ++dir)
             {
                 const std::string sfx = "_l" + std::to_string(l) + (dir ? "_reverse" : "");
@@ -557,7 +677,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                             const int col = u * 4 + g; // the 4 gates of a unit share a DPP quad
                             const size_t n = (size_t)dir * G + (size_t)sl * 64 + col;
                             rowmap[sl * 64 + col] = row;
-                            if (!ih_q)
+                            if (!ih_q && !gemm_planes)
                                 memcpy(&ihw[n * H], &wih[(size_t)row * H], sizeof(float) * H);
                             ihb[n] = bih[row];
                             bhh_h[l][((size_t)chain * S + sl) * 64 + col] = bhhv[row];
@@ -570,7 +690,18 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                                     whh_h[l][di] = whhv[(size_t)row * Hl + k];
                             }
                         }
-                if (ih_q)
+                if (gemm_planes)
+                {
+                    if (ih_exact)
+                    {
+                        fill_planes(ih_planes, 1, (size_t)2 * G, H, ihv[dir], nullptr, G, H, &rowmap, (size_t)dir * G);
+                        b.ih_p[l].s[dir] = ihv[dir]->scale;
+                        b.ih_p[l].o2[dir] = ihv[dir]->offset + 128.0f * ihv[dir]->scale;
+                    }
+                    else
+                        fill_planes(ih_planes, 3, (size_t)2 * G, H, nullptr, wih.data(), G, H, &rowmap, (size_t)dir * G);
+                }
+                else if (ih_q)
                 {
                     if (int rc = upload_q(&b.ih_q[l].q, ihv[dir], G, H, G, H, &rowmap, (size_t)dir * G, (size_t)2 * G))
                         return rc;
@@ -579,7 +710,12 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                     b.ih_q[l].o[dir] = ihv[dir]->offset;
                 }
             }
-            if (!ih_q)
+            if (gemm_planes)
+            {
+                if (int rc = upload_pmat(b.ih_p[l], ih_planes, ih_exact ? 1 : 3))
+                    return rc;
+            }
+            else if (!ih_q)
             {
                 if (int rc = upload_matrix(&b.ih_w[l], &b.ih_bx[l], ihw))
                     return rc;
@@ -659,10 +795,16 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     {
         Slot &sl = slot[si];
         UMX_HIP_CHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        // Buffers that a launch covering several track lanes reads or writes (the batched LSTM kernel, the plane GEMMs
+        // with M = lanes x Tp) are ONE allocation per slot (and target), lane after lane at a constant stride.
+        float *x_all = nullptr, *mixmag_all = nullptr;
+        if (int rc = dalloc(&x_all, (size_t)B * Tp * KX))
+            return rc;
+        if (int rc = dalloc(&mixmag_all, (size_t)B * 2 * T * NBINS))
+            return rc;
         for (int tg = 0; tg < 4; ++tg)
         {
-            // what the batched LSTM launch reads / writes for every lane sits at a constant lane stride
-            float *cat_all = nullptr, *la_all = nullptr, *lb_all = nullptr, *P_all = nullptr;
+            float *cat_all = nullptr, *la_all = nullptr, *lb_all = nullptr, *P_all = nullptr, *a2_all = nullptr, *mag_all = nullptr;
             if (int rc = dalloc(&cat_all, (size_t)B * Tp * 2 * H))
                 return rc;
             if (int rc = dalloc(&la_all, (size_t)B * Tp * H))
@@ -671,6 +813,25 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 return rc;
             if (int rc = dalloc(&P_all, (size_t)B * Tp * 4 * H))
                 return rc;
+            if (int rc = dalloc(&a2_all, (size_t)B * Tp * H))
+                return rc;
+            if (int rc = dalloc(&mag_all, (size_t)B * 2 * T * NBINS))
+                return rc;
+            unsigned short *xs_p = nullptr, *cat_p = nullptr, *la_p = nullptr, *lb_p = nullptr, *a2_p = nullptr;
+            float *rs[6] = {};
+            if (gemm_planes) // planes [3][B * Tp][K]: plane-major over ALL lanes, so that M runs across the lanes
+            {
+                if (int rc = dalloc(&xs_p, (size_t)3 * B * Tp * KX))
+                    return rc;
+                if (int rc = dalloc(&cat_p, (size_t)3 * B * Tp * 2 * H))
+                    return rc;
+                for (unsigned short **q : {&la_p, &lb_p, &a2_p})
+                    if (int rc = dalloc(q, (size_t)3 * B * Tp * H))
+                        return rc;
+                for (int k = 0; k < 6; ++k)
+                    if (int rc = dalloc(&rs[k], (size_t)B * Tp))
+                        return rc;
+            }
             for (int ln = 0; ln < B; ++ln)
             {
                 TargetAct &b = sl.lane[ln].ta[tg];
@@ -678,20 +839,30 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 b.la = la_all + (size_t)ln * Tp * H;
                 b.lb = lb_all + (size_t)ln * Tp * H;
                 b.P = P_all + (size_t)ln * Tp * 4 * H;
-                if (int rc = dalloc(&b.a2, (size_t)Tp * H))
-                    return rc;
-                if (int rc = dalloc(&b.mag, (size_t)2 * T * NBINS))
-                    return rc;
+                b.a2 = a2_all + (size_t)ln * Tp * H;
+                b.mag = mag_all + (size_t)ln * 2 * T * NBINS;
+                if (gemm_planes) // lane ln's rows start at row ln * Tp of every plane
+                {
+                    b.xs_p = xs_p + (size_t)ln * Tp * KX;
+                    b.cat_p = cat_p + (size_t)ln * Tp * 2 * H;
+                    b.la_p = la_p + (size_t)ln * Tp * H;
+                    b.lb_p = lb_p + (size_t)ln * Tp * H;
+                    b.a2_p = a2_p + (size_t)ln * Tp * H;
+                    b.rs_xs = rs[0] + (size_t)ln * Tp;
+                    b.rs_catL = rs[1] + (size_t)ln * Tp;
+                    b.rs_catR = rs[2] + (size_t)ln * Tp;
+                    b.rs_la = rs[3] + (size_t)ln * Tp;
+                    b.rs_lb = rs[4] + (size_t)ln * Tp;
+                    b.rs_a2 = rs[5] + (size_t)ln * Tp;
+                }
             }
         }
         for (int ln = 0; ln < B; ++ln)
         {
             Lane &L = sl.lane[ln];
+            L.x = x_all + (size_t)ln * Tp * KX;
+            L.mix_mag = mixmag_all + (size_t)ln * 2 * T * NBINS;
             if (int rc = dalloc(&L.spec, (size_t)2 * T * NBINS))
-                return rc;
-            if (int rc = dalloc(&L.mix_mag, (size_t)2 * T * NBINS))
-                return rc;
-            if (int rc = dalloc(&L.x, (size_t)Tp * KX))
                 return rc;
             if (int rc = dalloc(&L.y, (size_t)4 * 2 * T * NBINS))
                 return rc;
@@ -781,6 +952,17 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC3, BQ_U16>)};
         for (const void *fn : bxs)
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
+#define UMX_GP_ATTR(MODE)                                                                                              \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 1))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 2))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 3, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 3))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
+        UMX_GP_ATTR(G_FC1)
+        UMX_GP_ATTR(G_IH)
+        UMX_GP_ATTR(G_FC2)
+        UMX_GP_ATTR(G_FC3)
+#undef UMX_GP_ATTR
     }
     UMX_HIP_CHECK(hipDeviceSynchronize());
     return UMX_OK;
@@ -1098,6 +1280,155 @@ void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, con
 #undef UMX_LAUNCH
 }
 
+// gemm_planes.h: split one A operand of every active target into bf16 planes + row sums
+// ln = the first of nl consecutive track lanes (their buffers are contiguous: see init)
+void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, const int *active, int nact)
+{
+    SplitArgs a;
+    memset(&a, 0, sizeof a);
+    a.T = T;
+    a.Tp = Tp;
+    const size_t rows_all = (size_t)B * Tp; // rows of one output plane
+    for (int i = 0; i < nact; ++i)
+    {
+        const TargetBufs &b = tb[active[i]];
+        const TargetAct &c = ln.ta[active[i]];
+        switch (which)
+        {
+        case SP_XS: // x * input_scale + input_mean (inference.cpp:78-83), per target
+            a.src[i] = ln.x; a.dst[i] = c.xs_p; a.rowsum[i] = c.rs_xs; a.scale[i] = b.in_scale; a.mean[i] = b.in_mean;
+            a.cols = KX; a.ld_src = KX; a.ld_dst = KX; a.col0_dst = 0; a.plane = rows_all * KX;
+            break;
+        case SP_CATL: // fc1 output = left half of the skip concat
+            a.src[i] = c.cat; a.dst[i] = c.cat_p; a.rowsum[i] = c.rs_catL;
+            a.cols = H; a.ld_src = 2 * H; a.ld_dst = 2 * H; a.col0_dst = 0; a.plane = rows_all * 2 * H;
+            break;
+        case SP_CATR: // last LSTM layer's output = right half
+            a.src[i] = c.cat + H; a.dst[i] = c.cat_p; a.rowsum[i] = c.rs_catR;
+            a.cols = H; a.ld_src = 2 * H; a.ld_dst = 2 * H; a.col0_dst = H; a.plane = rows_all * 2 * H;
+            break;
+        case SP_LA:
+            a.src[i] = c.la; a.dst[i] = c.la_p; a.rowsum[i] = c.rs_la;
+            a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
+            break;
+        case SP_LB:
+            a.src[i] = c.lb; a.dst[i] = c.lb_p; a.rowsum[i] = c.rs_lb;
+            a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
+            break;
+        default:
+            a.src[i] = c.a2; a.dst[i] = c.a2_p; a.rowsum[i] = c.rs_a2;
+            a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
+            break;
+        }
+    }
+    hipLaunchKernelGGL(split_planes_kernel, dim3(nl * Tp, 1, nact), dim3(256), 0, st, a);
+}
+
+void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg)
+{
+    GemmPArgs g;
+    memset(&g, 0, sizeof g);
+    g.M = nl * Tp;
+    g.T = T;
+    g.Tp_lane = Tp;
+    g.mag_lane = (size_t)2 * T * NBINS;
+    g.dbg_lane = (size_t)T * NOUT;
+    const size_t rows_all = (size_t)B * Tp;
+    int nbp = 3;
+    for (int i = 0; i < nact; ++i)
+    {
+        const TargetBufs &b = tb[active[i]];
+        const TargetAct &c = ln.ta[active[i]];
+        GemmPTarget &t = g.t[i];
+        const PMat *pm = nullptr;
+        t.bsplit = 0x7fffffff;
+        switch (mode)
+        {
+        case G_FC1:
+            pm = &b.fc1_p;
+            t.A = c.xs_p; t.C = c.cat; t.rs0 = c.rs_xs;
+            t.e0 = b.bn1[0]; t.e1 = b.bn1[1]; t.e2 = b.bn1[2]; t.e3 = b.bn1[3];
+            g.N = H; g.K = KX; g.lda = KX; g.ldc = 2 * H; g.a_plane = rows_all * KX;
+            break;
+        case G_IH:
+            pm = &b.ih_p[layer];
+            t.A = layer == 0 ? c.cat_p : layer == 1 ? c.la_p : c.lb_p;
+            t.rs0 = layer == 0 ? c.rs_catL : layer == 1 ? c.rs_la : c.rs_lb;
+            t.C = c.P; t.e0 = b.ih_b[layer];
+            t.bsplit = 2 * H; // W_ih rows >= 4*Hl belong to the reverse direction's tensor
+            g.N = 4 * H; g.K = H; g.lda = layer == 0 ? 2 * H : H; g.ldc = 4 * H;
+            g.a_plane = layer == 0 ? rows_all * 2 * H : rows_all * H;
+            break;
+        case G_FC2:
+            pm = &b.fc2_p;
+            t.A = c.cat_p; t.C = c.a2; t.rs0 = c.rs_catL; t.rs1 = c.rs_catR;
+            t.e0 = b.bn2[0]; t.e1 = b.bn2[1]; t.e2 = b.bn2[2]; t.e3 = b.bn2[3];
+            g.N = H; g.K = 2 * H; g.lda = 2 * H; g.ldc = H; g.a_plane = rows_all * 2 * H;
+            break;
+        default:
+            pm = &b.fc3_p;
+            t.A = c.a2_p; t.C = c.mag; t.rs0 = c.rs_a2;
+            t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
+            t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = ln.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
+            g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0; g.a_plane = rows_all * H;
+            break;
+        }
+        t.B = pm->p;
+        t.bs[0] = pm->s[0]; t.bs[1] = pm->s[1];
+        t.bo2[0] = pm->o2[0]; t.bo2[1] = pm->o2[1];
+        nbp = pm->nbp; // the same for every target (all_q at create)
+    }
+    // 256 x 256 tiles (half the L2 traffic per flop) when they fill the chip; fp32 weights (three planes) do not fit LDS there
+    const int blocks_big = (g.N / 256) * (g.M / 256) * nact;
+    const bool big = nbp < 3 && g.N % 256 == 0 && blocks_big >= 224;
+    const int bm = big ? 256 : 128;
+    const dim3 grid((unsigned)round_up((g.N / bm) * (g.M / bm), 8), 1, nact), block(big ? 1024 : 256);
+    const size_t lds = big ? gp_lds_bytes(4, 4, nbp) : gp_lds_bytes(2, 2, nbp);
+#define UMX_GP(MODE)                                                                                                 \
+    if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);           \
+    else if (big) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 4, 4>), grid, block, lds, st, g);                  \
+    else if (nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 2, 2>), grid, block, lds, st, g);             \
+    else if (nbp == 2) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 2>), grid, block, lds, st, g);             \
+    else hipLaunchKernelGGL((gemm_planes_kernel<MODE, 3, 2, 2>), grid, block, lds, st, g);
+    switch (mode)
+    {
+    case G_FC1: UMX_GP(G_FC1) break;
+    case G_IH: UMX_GP(G_IH) break;
+    case G_FC2: UMX_GP(G_FC2) break;
+    default: UMX_GP(G_FC3) break;
+    }
+#undef UMX_GP
+}
+
+void umx_hip_ctx::launch_gemm_lanes(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, int mode, int layer,
+                                    const int *active, int nact, bool dbg)
+{
+    if (nact <= 0)
+        return;
+    for (int l0 = 0; l0 < nb;)
+    {
+        if (!audio_dev[l0])
+        {
+            ++l0;
+            continue;
+        }
+        int l1 = l0 + 1;
+        while (gemm_planes && l1 < nb && audio_dev[l1])
+            ++l1;
+        if (gemm_planes)
+        {
+            // the A operand is split here, right before its consumer (every producer -- STFT, fc1, the LSTM layers,
+            // fc2 -- writes fp32)
+            launch_split(sl.lane[l0], l1 - l0, st, mode == G_FC1 ? SP_XS : mode == G_IH ? (layer == 0 ? SP_CATL : layer == 1 ? SP_LA : SP_LB)
+                                                                   : mode == G_FC2 ? SP_CATR : SP_A2, active, nact);
+            launch_gemm_planes(sl.lane[l0], l1 - l0, st, mode, layer, active, nact, dbg);
+        }
+        else
+            launch_gemm(sl.lane[l0], st, mode, layer, active, nact, dbg);
+        l0 = l1;
+    }
+}
+
 // stft -> |.|, crop/stack -> fc1/bn1/tanh -> input projection of LSTM layer 0; stage by stage over the track lanes
 int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active,
                              int nact)
@@ -1112,15 +1443,9 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
                                L.mix_mag, L.x, L.maxabs);
         }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
-    if (nact > 0)
-        for (int ln = 0; ln < nb; ++ln)
-            if (audio_dev[ln])
-                launch_gemm(sl.lane[ln], st, G_FC1, 0, active, nact, false);
+    launch_gemm_lanes(sl, st, nb, audio_dev, G_FC1, 0, active, nact, false);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
-    if (nact > 0)
-        for (int ln = 0; ln < nb; ++ln)
-            if (audio_dev[ln])
-                launch_gemm(sl.lane[ln], st, G_IH, 0, active, nact, false);
+    launch_gemm_lanes(sl, st, nb, audio_dev, G_IH, 0, active, nact, false);
     return UMX_OK;
 }
 
@@ -1130,15 +1455,9 @@ int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const
 {
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
-    if (nact > 0)
-        for (int ln = 0; ln < nb; ++ln)
-            if (audio_dev[ln])
-                launch_gemm(sl.lane[ln], st, G_FC2, 0, active, nact, dbg);
+    launch_gemm_lanes(sl, st, nb, audio_dev, G_FC2, 0, active, nact, dbg);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
-    if (nact > 0)
-        for (int ln = 0; ln < nb; ++ln)
-            if (audio_dev[ln])
-                launch_gemm(sl.lane[ln], st, G_FC3, 0, active, nact, dbg);
+    launch_gemm_lanes(sl, st, nb, audio_dev, G_FC3, 0, active, nact, dbg);
     for (int ln = 0; ln < nb; ++ln)
         if (audio_dev[ln])
             for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
@@ -1245,11 +1564,15 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
     active_list(flags, active, nact);
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
     if (dbg)
-        for (int ln = 0; ln < nb; ++ln)
-            for (int tg = 0; tg < 4; ++tg)
-                if (!sl.lane[ln].ta[tg].mask_dbg)
-                    if (int rc = dalloc(&sl.lane[ln].ta[tg].mask_dbg, (size_t)T * NOUT))
-                        return rc;
+        for (int tg = 0; tg < 4; ++tg)
+            if (!sl.lane[0].ta[tg].mask_dbg)
+            {
+                float *all = nullptr;
+                if (int rc = dalloc(&all, (size_t)B * T * NOUT))
+                    return rc;
+                for (int ln = 0; ln < B; ++ln)
+                    sl.lane[ln].ta[tg].mask_dbg = all + (size_t)ln * T * NOUT;
+            }
     last_flags = flags;
     if (int rc = stage_front(sl, st, nb, audio_dev, n, active, nact))
         return rc;
@@ -1261,10 +1584,7 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
         if (layer > 0)
         {
             UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
-            if (nact > 0)
-                for (int ln = 0; ln < nb; ++ln)
-                    if (audio_dev[ln])
-                        launch_gemm(sl.lane[ln], st, G_IH, layer, active, nact, false);
+            launch_gemm_lanes(sl, st, nb, audio_dev, G_IH, layer, active, nact, false);
         }
         if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3)
             UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[two_grids ? layer : 2], 0));
@@ -1490,8 +1810,10 @@ int umx_hip_ctx::phase_layer(int layer)
     if (layer > 0)
     {
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
-        if (nact > 0)
-            launch_gemm(sl.lane[0], st, G_IH, layer, active, nact, false);
+        {
+            const float *ain = audio_in;
+            launch_gemm_lanes(sl, st, 1, &ain, G_IH, layer, active, nact, false);
+        }
     }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
     if (nact > 0)
@@ -1566,8 +1888,12 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
         if (std::string(e) == "expanded" || std::string(e) == "f32")
             cf |= UMX_CREATE_DEQUANTISE_AT_LOAD;
     if (const char *e = getenv("UMX_GEMM"))
+    {
         if (std::string(e) == "f32")
             cf |= UMX_CREATE_GEMM_F32;
+        if (std::string(e) == "bf16x3")
+            cf |= UMX_CREATE_GEMM_STAGED;
+    }
     if (const char *e = getenv("UMX_LSTM"))
         if (std::string(e) == "batched")
             cf |= UMX_CREATE_LSTM_BATCHED;

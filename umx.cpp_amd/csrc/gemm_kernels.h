@@ -53,6 +53,10 @@ struct GemmArgs
 {
     GemmTarget t[4];
     int M, N, K, lda, ldc, T;
+    // several track lanes in one launch (gemm_planes.h): M = lanes x Tp_lane rows; the FC3 epilogue's per-lane buffers
+    // (mix magnitude in, target magnitude out, mask tap) then sit mag_lane / dbg_lane floats apart.  0 = one lane.
+    int Tp_lane;
+    size_t mag_lane, dbg_lane;
 };
 
 // Knob: pin the next tile's global loads at the top of the K tile with sched_barrier (consumers are deferred
@@ -123,14 +127,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
                         tg.C[(size_t)m * args.ldc + n] = tanhf(y);
                     else if (MODE == G_FC2)
                         tg.C[(size_t)m * args.ldc + n] = fmaxf(y, 0.f);
-                    else if (n < NOUT && m < args.T)
+                    else if (n < NOUT)
                     {
-                        y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
-                        if (tg.dbg)
-                            tg.dbg[(size_t)m * NOUT + n] = y;
-                        const int c = n >= NBINS ? 1 : 0, b = n - c * NBINS;
-                        const size_t idx = ((size_t)c * args.T + m) * NBINS + b;
-                        tg.C[idx] = y * tg.aux[idx]; // inference.cpp:175-183
+                        int f = m;
+                        size_t lo = 0, ld = 0;
+                        if (args.Tp_lane)
+                        {
+                            const int ln = m / args.Tp_lane;
+                            f = m - ln * args.Tp_lane;
+                            lo = (size_t)ln * args.mag_lane;
+                            ld = (size_t)ln * args.dbg_lane;
+                        }
+                        if (f < args.T)
+                        {
+                            y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
+                            if (tg.dbg)
+                                tg.dbg[ld + (size_t)f * NOUT + n] = y;
+                            const int c = n >= NBINS ? 1 : 0, b = n - c * NBINS;
+                            const size_t idx = lo + ((size_t)c * args.T + f) * NBINS + b;
+                            tg.C[idx] = y * tg.aux[idx]; // inference.cpp:175-183
+                        }
                     }
                 }
             }
