@@ -434,19 +434,27 @@ def main():
 
 def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
     """BASELINE config 4: ONE 600 s track, its 14 segments round-robin over the ranks with the exact per-layer (h, c)
-    hand-off (multigpu.separate_track_carry_mode), weighted stems gathered on rank 0.  A step = the whole track."""
+    hand-off, weighted stems gathered on rank 0: the C++17 driver of include/umx_mgpu.h (RCCL send / recv on device
+    pointers, no host bounce).  A step = the whole track, host buffers in and out."""
     import torch
     N = args.segment_samples
     eng = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank)
     secs = args.track_seconds or 600.0
     L = int(secs * 44100)
     wave = pkg.ggml.synth_audio(L, 99)
-    backend = mg.EnginePhases(eng)
+    ids = None
+    if world > 1:  # RCCL rendezvous ids: made on rank 0, broadcast over the process group that is already up
+        t = torch.zeros(pkg.MGPU_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(pkg.mgpu_unique_id()), dtype=torch.uint8).clone().to(dev)
+        dist.broadcast(t, src=0)
+        ids = bytes(t.cpu().numpy().tobytes())
+    drv = pkg.MultiGpuTrack(eng, rank, world, ids)
     dd = dist if world > 1 else None
     res = [None]
 
     def step():
-        res[0] = mg.separate_track_carry_mode(backend, wave, N, dist=dd, rank=rank, world=world, device=dev)
+        res[0] = drv.separate(wave, shift_offset=4033)
 
     def fence():
         eng.sync()
@@ -454,15 +462,20 @@ def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
     steps, warmup = max(1, min(args.steps, 4)), max(1, min(args.warmup, 1))
     dt = mg.timed_region(step, fence, steps, warmup, dist=dd, world=world, device=dev)
     if rank == 0:
+        nseg = -(-(L + 22050 - 4033) // int(0.75 * N))
         line = {"metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg", "value": round(steps * secs / dt, 2),
                 "unit": "x realtime", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"UMX-L full-track segmented inference: one {secs:g} s track, {-(-L // int(0.75 * N))} segments "
-                                       f"round-robin over {world} MI355X, exact LSTM state carry (per-layer (h, c) point to point), "
-                                       "overlap-add gather on rank 0; host buffers in and out (BASELINE config 4)",
-                           "hidden": args.hidden, "segment_samples": N, "parallelism": f"segments over {world} ranks, carry mode"},
+                "config": {"workload": f"UMX-L full-track segmented inference: one {secs:g} s track, {nseg} segments round-robin over "
+                                       f"{world} MI355X, exact LSTM state carry (per-layer (h, c) by RCCL send/recv between the engines' "
+                                       "HBM state buffers), weighted stems gathered and overlap-added on rank 0 (second communicator); "
+                                       "host buffers in and out (BASELINE config 4)",
+                           "hidden": args.hidden, "segment_samples": N, "segments": nseg,
+                           "parallelism": f"segments over {world} ranks, carry mode; at most 3 segments per target are in flight "
+                                          "(one per LSTM layer), so one track cannot fill more than ~3 GPUs"},
                 "outputs_finite": bool(all(np.isfinite(r).all() for r in res[0]))}
         print(json.dumps(line), flush=True)
+    drv.close()
     eng.close()
     if world > 1:
         dist.barrier()

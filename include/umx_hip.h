@@ -194,6 +194,28 @@ int umx_hip_segment_begin(umx_hip_ctx *ctx, const float *audio_host, int n, unsi
 int umx_hip_segment_lstm_layer(umx_hip_ctx *ctx, int layer); /* 0, 1, 2 in order */
 int umx_hip_segment_end(umx_hip_ctx *ctx, float *const out_host[4]);
 
+/* The same cut points for a driver that keeps everything in HBM and on ONE stream (host/mgpu.cpp: RCCL send / recv
+ * of the state and of the weighted stems on device pointers, no host bounce).  None of these waits for the device;
+ * all work is queued on umx_hip_phase_stream in call order, so a collective queued on that stream between two of
+ * them is ordered against the kernels on both sides.
+ *   umx_hip_segment_begin_device   front of a segment, audio already in HBM
+ *   umx_hip_segment_lstm_layer     (as above)
+ *   umx_hip_segment_end_device     back of the segment into 4 device buffers (2,n)
+ *   umx_hip_stream_state_device    device address of track lane 0's stream state, [4 targets][3 layers][2 dirs][2: h, c][hidden/2]:
+ *                                  layer l of target t is the 4 * hidden/2 floats at ((t * 3 + l) * 4) * hidden/2
+ *   umx_hip_weight_stems_device    stems[t][k] *= transition weight of sample k (umx.cpp:197-206, 246), in place
+ *   umx_hip_track_accumulate_device / _normalise_device   umx.cpp:234-273 on device buffers: track (2,length) x 4 +=
+ *                                  already weighted stems at `offset`, sum_weight += weights; then track /= sum_weight */
+void *umx_hip_phase_stream(umx_hip_ctx *ctx);
+float *umx_hip_stream_state_device(umx_hip_ctx *ctx);
+int umx_hip_segment_begin_device(umx_hip_ctx *ctx, const float *audio_dev, int n, unsigned flags);
+int umx_hip_segment_end_device(umx_hip_ctx *ctx, float *const out_dev[4]);
+int umx_hip_weight_stems_device(umx_hip_ctx *ctx, float *const stems_dev[4], int n, void *hip_stream);
+int umx_hip_track_accumulate_device(umx_hip_ctx *ctx, float *const track_dev[4], float *sum_weight_dev,
+                                    const float *const weighted_dev[4], int offset, int n, void *hip_stream);
+int umx_hip_track_normalise_device(umx_hip_ctx *ctx, float *const track_dev[4], const float *sum_weight_dev, int length,
+                                   void *hip_stream);
+
 /* Geometry */
 int umx_hip_nb_frames(const umx_hip_ctx *ctx);       /* T = segment_samples/1024 + 1 (dsp.hpp:48) */
 int umx_hip_segment_samples(const umx_hip_ctx *ctx);

@@ -76,6 +76,37 @@ int umx_shift_inference(const umx_backend *be, const float *audio, int length, i
                         int offset, float *const out[4], void (*progress)(float, void *), void *progress_user,
                         char *err);
 
+/* ---- one track over several ranks, EXACT ("carry" mode).  split_inference's segments (umx.cpp:214-227) go
+ * round-robin over `world` ranks; the reference carries every LSTM chain's (h, c) from one segment into the next
+ * (umx.cpp:167-171, lstm.cpp:139-161: SURVEY F3) and layer l of segment s needs nothing else of segment s-1, so rank
+ * s % world runs segment s phase by phase: before LSTM layer l it receives that layer's state from the rank that ran
+ * segment s-1 and afterwards sends its own on.  Rank 0 gathers the weighted stems in segment order (each output
+ * sample has at most two contributors), adds them exactly like umx.cpp:234-260 and normalises.  All traffic is point
+ * to point; there is no collective.  Bit-identical to umx_split_inference on one rank.
+ * The backend is the phased form of the per-segment call (include/umx_hip.h: umx_hip_segment_begin / _lstm_layer /
+ * _end + umx_hip_stream_{get,set}_layer); the transport moves float buffers between ranks (blocking or buffered
+ * sends both work: the dependency graph follows segment order).  This host-buffer form is what the CPU tests drive
+ * (torch.distributed gloo through callbacks); host/mgpu.cpp is the same schedule with device buffers over RCCL. */
+typedef struct umx_phased_backend
+{
+    int (*begin)(void *user, const float *audio, int n);     /* front of a segment: STFT, fc1, W_ih of layer 0 */
+    int (*layer)(void *user, int l);                          /* LSTM layer l (0, 1, 2 in order) */
+    int (*end)(void *user, float *const out[4]);              /* fc2 ... iSTFT: 4 x (2,n) */
+    int (*get_layer)(void *user, int l, float *state);        /* layer_floats values */
+    int (*set_layer)(void *user, int l, const float *state);
+    size_t layer_floats;
+    void *user;
+} umx_phased_backend;
+typedef struct umx_p2p
+{
+    int (*send)(void *user, const float *buf, size_t n, int dst);
+    int (*recv)(void *user, float *buf, size_t n, int src);
+    void *user;
+} umx_p2p;
+/* out[4] (2,length) is written on rank 0 only (may be NULL elsewhere). */
+int umx_split_inference_carry(const umx_phased_backend *be, const umx_p2p *p2p, int rank, int world, const float *audio,
+                              int length, int segment_samples, float *const out[4], char *err);
+
 /* Plan of a track: the (offset, length) of every segment split_inference will run (umx.cpp:214-218),
  * used by the multi-GPU scheduler.  Returns the number of segments; fills up to cap entries. */
 int umx_segment_plan(int length, int segment_samples, int *offsets, int *lengths, int cap);

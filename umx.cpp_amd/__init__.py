@@ -140,7 +140,9 @@ MAX_TRACKS = 16
 HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "umx_hip_n_tracks", "umx_hip_lstm_is_batched",
                "umx_hip_track_stream_reset", "umx_hip_track_stream_get", "umx_hip_track_stream_set",
                "umx_hip_infer_segment_async", "umx_hip_infer_batch", "umx_hip_infer_batch_async",
-               "umx_hip_infer_batch_device", "umx_hip_order_after", "umx_hip_order_before", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
+               "umx_hip_infer_batch_device", "umx_hip_order_after", "umx_hip_order_before",
+               "umx_hip_phase_stream", "umx_hip_stream_state_device", "umx_hip_segment_begin_device", "umx_hip_segment_end_device",
+               "umx_hip_weight_stems_device", "umx_hip_track_accumulate_device", "umx_hip_track_normalise_device", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
@@ -424,11 +426,29 @@ class Engine:
 HOST_SYMBOLS = ["umx_model_load", "umx_model_free", "umx_model_hidden", "umx_model_n_tensors", "umx_model_views",
                 "umx_model_data_bytes", "umx_model_load_progress", "umx_model_dequantize", "umx_wav_load",
                 "umx_wav_free", "umx_wav_write_f32", "umx_split_inference", "umx_shift_inference",
-                "umx_segment_plan", "umx_transition_weight"]
+                "umx_segment_plan", "umx_transition_weight", "umx_split_inference_carry"]
 
 SEGMENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int, C.POINTER(_fp))
 RESET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_float, C.c_void_p)
+
+
+PH_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int)
+PH_LAYER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+PH_END_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_fp))
+PH_STATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _fp)
+P2P_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_size_t, C.c_int)
+
+
+class PhasedBackend(C.Structure):
+    """include/umx_host.h: umx_phased_backend"""
+    _fields_ = [("begin", PH_BEGIN_FN), ("layer", PH_LAYER_FN), ("end", PH_END_FN), ("get_layer", PH_STATE_FN),
+                ("set_layer", PH_STATE_FN), ("layer_floats", C.c_size_t), ("user", C.c_void_p)]
+
+
+class P2P(C.Structure):
+    """include/umx_host.h: umx_p2p"""
+    _fields_ = [("send", P2P_FN), ("recv", P2P_FN), ("user", C.c_void_p)]
 
 
 class Backend(C.Structure):
@@ -466,6 +486,8 @@ def host_lib():
                                         C.c_void_p, C.c_char_p]
     lib.umx_shift_inference.argtypes = [C.POINTER(Backend), _fp, C.c_int, C.c_int, C.c_int, C.POINTER(_fp),
                                         PROGRESS_FN, C.c_void_p, C.c_char_p]
+    lib.umx_split_inference_carry.argtypes = [C.POINTER(PhasedBackend), C.POINTER(P2P), C.c_int, C.c_int, _fp, C.c_int, C.c_int,
+                                              C.POINTER(_fp), C.c_char_p]
     lib.umx_segment_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     lib.umx_transition_weight.restype = C.c_float
     lib.umx_transition_weight.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -618,3 +640,76 @@ def shift_inference(backend, wave, segment_samples=SEGMENT_SAMPLES, offset=None,
 
 def engine_backend(eng, flags=0):
     return make_backend(lambda w: eng.infer_segment(w, flags), eng.stream_reset)
+
+
+# ------------------------------------------------------------------ multi-GPU track driver (umx_mgpu.h)
+MGPU_SYMBOLS = ["umx_mgpu_unique_id", "umx_mgpu_create", "umx_mgpu_destroy", "umx_mgpu_separate_track"]
+MGPU_ID_BYTES = 256
+_mgpu = None
+
+
+def mgpu_lib():
+    """libumx_mgpu.so: C++17 host over RCCL (loads librccl; a process that never shards a track does not need it)."""
+    global _mgpu
+    if _mgpu is not None:
+        return _mgpu
+    hip_lib()
+    path = HERE / "libumx_mgpu.so"
+    if not path.exists():
+        raise ImportError(f"{path} is missing: run __graft_entry__.build()")
+    lib = C.CDLL(str(path))
+    lib.umx_mgpu_unique_id.argtypes = [C.c_char_p, C.c_char_p]
+    lib.umx_mgpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    lib.umx_mgpu_destroy.argtypes = [C.c_void_p]
+    lib.umx_mgpu_separate_track.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(_fp), C.c_uint, C.c_char_p]
+    _mgpu = lib
+    return lib
+
+
+def mgpu_unique_id():
+    buf = C.create_string_buffer(MGPU_ID_BYTES)
+    err = C.create_string_buffer(256)
+    rc = mgpu_lib().umx_mgpu_unique_id(buf, err)
+    if rc:
+        raise UmxError(rc, err.value.decode())
+    return buf.raw
+
+
+class MultiGpuTrack:
+    """One track over `world` GPUs, exact (include/umx_mgpu.h): rank s % world runs segment s, LSTM layer states and
+    weighted stems travel over RCCL point to point on device pointers.  ids: the bytes of mgpu_unique_id() made on
+    rank 0 and handed to every rank (None when world == 1)."""
+
+    def __init__(self, engine, rank=0, world=1, ids=None):
+        self.lib, self.eng, self.rank = mgpu_lib(), engine, rank
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        rc = self.lib.umx_mgpu_create(C.byref(h), engine.h, rank, world, ids, err)
+        if rc:
+            raise UmxError(rc, err.value.decode())
+        self.h = h
+
+    def separate(self, wave, shift_offset=None, flags=0):
+        """(2,L) host array on every rank -> 4 x (2,L) on rank 0 (None elsewhere); collective over the ranks."""
+        wave = np.asarray(wave, np.float32)
+        L = wave.shape[1]
+        a = np.ascontiguousarray(wave.T).ravel()
+        outs = [np.empty(2 * L, np.float32) for _ in range(4)] if self.rank == 0 else None
+        arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs]) if outs else None
+        err = C.create_string_buffer(256)
+        rc = self.lib.umx_mgpu_separate_track(self.h, a.ctypes.data_as(_fp), L, -1 if shift_offset is None else shift_offset,
+                                              arr, flags, err)
+        if rc:
+            raise UmxError(rc, err.value.decode())
+        return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs] if outs else None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.umx_mgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

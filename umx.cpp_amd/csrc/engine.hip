@@ -237,6 +237,9 @@ struct umx_hip_ctx
     size_t trk_cap = 0; // samples the track buffers hold
     hipEvent_t trk_acc_ev[2] = {};
     int phase_begin(const float *audio_host, int n, unsigned flags);
+    int phase_begin_device(const float *audio_dev, int n, unsigned flags);
+    int phase_end_device(float *const out_dev_[4]);
+    const float *ph_audio = nullptr;
     int phase_layer(int layer);
     int phase_end(float *const out_host[4]);
     int ph_next = -1; // -1: no phased segment open; 0..2: next LSTM layer; 3: back stage pending
@@ -1792,6 +1795,54 @@ int umx_hip_ctx::phase_begin(const float *audio_host, int n, unsigned flags)
     ph_next = 0;
     ph_n = n;
     ph_flags = flags;
+    ph_audio = nullptr;
+    return UMX_OK;
+}
+
+// the same without host transfers and without waiting (multi-GPU driver: everything stays on slot 0's stream)
+int umx_hip_ctx::phase_begin_device(const float *audio_dev, int n, unsigned flags)
+{
+    if (!audio_dev || n < 1 || n > N)
+    {
+        set_error("segment_begin_device: need 1 <= n <= segment_samples and non-null audio");
+        return UMX_ERR_ARG;
+    }
+    if (ph_next != -1)
+    {
+        set_error("segment_begin: a phased segment is already open");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    Slot &sl = slot[0];
+    int active[4], nact;
+    active_list(flags, active, nact);
+    last_flags = flags;
+    if (int rc = stage_front(sl, sl.stream, 1, &audio_dev, &n, active, nact))
+        return rc;
+    ph_next = 0;
+    ph_n = n;
+    ph_flags = flags;
+    ph_audio = audio_dev;
+    return UMX_OK;
+}
+
+int umx_hip_ctx::phase_end_device(float *const out_dev_[4])
+{
+    if (ph_next != 3 || !out_dev_)
+    {
+        set_error("segment_end: all three LSTM layers must have run");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    Slot &sl = slot[0];
+    int active[4], nact;
+    active_list(ph_flags, active, nact);
+    ph_next = -1;
+    const float *ain = ph_audio ? ph_audio : audio_in;
+    if (int rc = stage_back(sl, sl.stream, 1, &ain, out_dev_, &ph_n, ph_flags, active, nact))
+        return rc;
+    cur = 0;
+    slot[0].used = slot[1].used = false;
     return UMX_OK;
 }
 
@@ -1811,7 +1862,7 @@ int umx_hip_ctx::phase_layer(int layer)
     {
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
         {
-            const float *ain = audio_in;
+            const float *ain = ph_audio ? ph_audio : audio_in;
             launch_gemm_lanes(sl, st, 1, &ain, G_IH, layer, active, nact, false);
         }
     }
@@ -2099,6 +2150,49 @@ int umx_hip_segment_begin(umx_hip_ctx *ctx, const float *audio_host, int n, unsi
 }
 int umx_hip_segment_lstm_layer(umx_hip_ctx *ctx, int layer) { return ctx ? ctx->phase_layer(layer) : UMX_ERR_ARG; }
 int umx_hip_segment_end(umx_hip_ctx *ctx, float *const out_host[4]) { return ctx ? ctx->phase_end(out_host) : UMX_ERR_ARG; }
+
+void *umx_hip_phase_stream(umx_hip_ctx *ctx) { return ctx ? (void *)ctx->slot[0].stream : nullptr; }
+float *umx_hip_stream_state_device(umx_hip_ctx *ctx) { return ctx ? ctx->state : nullptr; }
+int umx_hip_segment_begin_device(umx_hip_ctx *ctx, const float *audio_dev, int n, unsigned flags)
+{
+    return ctx ? ctx->phase_begin_device(audio_dev, n, flags) : UMX_ERR_ARG;
+}
+int umx_hip_segment_end_device(umx_hip_ctx *ctx, float *const out_dev[4]) { return ctx ? ctx->phase_end_device(out_dev) : UMX_ERR_ARG; }
+
+static Stems4 stems4(float *const p[4])
+{
+    Stems4 s;
+    for (int t = 0; t < 4; ++t)
+        s.p[t] = reinterpret_cast<float2 *>(p[t]);
+    return s;
+}
+int umx_hip_weight_stems_device(umx_hip_ctx *ctx, float *const stems_dev[4], int n, void *hip_stream)
+{
+    if (!ctx || !stems_dev || n < 1)
+        return UMX_ERR_ARG;
+    hipLaunchKernelGGL(track_weight_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, (hipStream_t)hip_stream, stems4(stems_dev), n, ctx->N);
+    return hipGetLastError() == hipSuccess ? UMX_OK : UMX_ERR_HIP;
+}
+int umx_hip_track_accumulate_device(umx_hip_ctx *ctx, float *const track_dev[4], float *sum_weight_dev,
+                                    const float *const weighted_dev[4], int offset, int n, void *hip_stream)
+{
+    if (!ctx || !track_dev || !sum_weight_dev || !weighted_dev || n < 1 || offset < 0)
+        return UMX_ERR_ARG;
+    float *w[4] = {const_cast<float *>(weighted_dev[0]), const_cast<float *>(weighted_dev[1]), const_cast<float *>(weighted_dev[2]),
+                   const_cast<float *>(weighted_dev[3])};
+    hipLaunchKernelGGL(track_add_weighted_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, (hipStream_t)hip_stream, stems4(track_dev),
+                       sum_weight_dev, stems4(w), offset, n, ctx->N);
+    return hipGetLastError() == hipSuccess ? UMX_OK : UMX_ERR_HIP;
+}
+int umx_hip_track_normalise_device(umx_hip_ctx *ctx, float *const track_dev[4], const float *sum_weight_dev, int length,
+                                   void *hip_stream)
+{
+    if (!ctx || !track_dev || !sum_weight_dev || length < 1)
+        return UMX_ERR_ARG;
+    hipLaunchKernelGGL(track_normalise_kernel, dim3((length + 255) / 256, 4), dim3(256), 0, (hipStream_t)hip_stream, stems4(track_dev),
+                       sum_weight_dev, 0, length);
+    return hipGetLastError() == hipSuccess ? UMX_OK : UMX_ERR_HIP;
+}
 
 int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
                                  unsigned flags)

@@ -36,6 +36,33 @@ __global__ void track_accumulate_kernel(Stems4 track, float *sum_w, Stems4 seg, 
         sum_w[(size_t)offset + k] += w;
 }
 
+// the two halves of that update for a multi-GPU driver: the rank that ran the segment multiplies (w * chunk, one
+// rounding), the rank that owns the track adds (a second rounding) -- the same two fp32 operations as above
+__global__ void track_weight_kernel(Stems4 seg, int n, int N)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (k >= n)
+        return;
+    const float w = transition_weight(k, N);
+    float2 s = seg.p[t][k];
+    s.x = w * s.x;
+    s.y = w * s.y;
+    seg.p[t][k] = s;
+}
+__global__ void track_add_weighted_kernel(Stems4 track, float *sum_w, Stems4 wseg, int offset, int n, int N)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (k >= n)
+        return;
+    const float2 s = wseg.p[t][k];
+    float2 o = track.p[t][(size_t)offset + k];
+    o.x += s.x;
+    o.y += s.y;
+    track.p[t][(size_t)offset + k] = o;
+    if (t == 0)
+        sum_w[(size_t)offset + k] += transition_weight(k, N);
+}
+
 // umx.cpp:264-273: out /= sum_weight, for samples [start, start + count)
 __global__ void track_normalise_kernel(Stems4 track, const float *sum_w, int start, int count)
 {

@@ -150,3 +150,126 @@ extern "C" int umx_shift_inference(const umx_backend *be, const float *audio, in
         memcpy(out[t], full[t].data() + (size_t)2 * offset, sizeof(float) * 2 * (size_t)length);
     return UMX_OK;
 }
+
+// ---------------------------------------------------------------- one track over several ranks (exact carry mode)
+extern "C" int umx_split_inference_carry(const umx_phased_backend *be, const umx_p2p *p2p, int rank, int world,
+                                         const float *audio, int length, int segment_samples, float *const out[4], char *err)
+{
+    if (!be || !be->begin || !be->layer || !be->end || !be->get_layer || !be->set_layer || !audio || length < 1 ||
+        segment_samples < 2 || world < 1 || rank < 0 || rank >= world || (world > 1 && (!p2p || !p2p->send || !p2p->recv)) ||
+        (rank == 0 && !out))
+    {
+        seterr(err, "umx_split_inference_carry: bad argument");
+        return UMX_ERR_ARG;
+    }
+    const int N = segment_samples, stride = (int)((1 - kOverlap) * N); // umx.cpp:181
+    std::vector<int> offsets;
+    for (long long off = 0; off < length; off += stride) // umx.cpp:214
+        offsets.push_back((int)off);
+    const int nseg = (int)offsets.size();
+    const size_t nf = be->layer_floats;
+    std::vector<float> st(nf);
+    std::vector<std::vector<float>> mine(nseg); // this rank's weighted stems, [4][2][n] per segment
+    for (int i = rank; i < nseg; i += world)
+    {
+        const int off = offsets[i], n = std::min(N, length - off); // umx.cpp:217
+        if (int rc = be->begin(be->user, audio + (size_t)2 * off, n))
+        {
+            seterr(err, "phased backend: begin failed");
+            return rc;
+        }
+        for (int l = 0; l < 3; ++l)
+        {
+            int rc = UMX_OK;
+            if (i == 0) // umx.cpp:167-171 / lstm.cpp:82: the track starts from zero state
+            {
+                std::fill(st.begin(), st.end(), 0.0f);
+                rc = be->set_layer(be->user, l, st.data());
+            }
+            else if (world > 1)
+            {
+                rc = p2p->recv(p2p->user, st.data(), nf, (i - 1) % world);
+                if (!rc)
+                    rc = be->set_layer(be->user, l, st.data());
+            } // world == 1: the state segment i-1 left is already in place
+            if (!rc)
+                rc = be->layer(be->user, l);
+            if (!rc && world > 1 && i + 1 < nseg)
+            {
+                rc = be->get_layer(be->user, l, st.data());
+                if (!rc)
+                    rc = p2p->send(p2p->user, st.data(), nf, (i + 1) % world);
+            }
+            if (rc)
+            {
+                seterr(err, "carry driver: layer " + std::to_string(l) + " of segment " + std::to_string(i) + " failed");
+                return rc;
+            }
+        }
+        std::vector<float> stems[4];
+        float *so[4];
+        for (int t = 0; t < 4; ++t)
+        {
+            stems[t].assign((size_t)2 * n, 0.0f);
+            so[t] = stems[t].data();
+        }
+        if (int rc = be->end(be->user, so))
+        {
+            seterr(err, "phased backend: end failed");
+            return rc;
+        }
+        mine[i].resize((size_t)4 * 2 * n);
+        for (int t = 0; t < 4; ++t)
+            for (int k = 0; k < n; ++k)
+            {
+                const float w = umx_transition_weight(k, n, N); // umx.cpp:246
+                mine[i][((size_t)t * n + k) * 2] = w * stems[t][2 * (size_t)k];
+                mine[i][((size_t)t * n + k) * 2 + 1] = w * stems[t][2 * (size_t)k + 1];
+            }
+    }
+    // gather on rank 0 in segment order (= the reference's accumulation order), umx.cpp:234-273
+    if (rank != 0)
+    {
+        for (int i = rank; i < nseg; i += world)
+            if (int rc = p2p->send(p2p->user, mine[i].data(), mine[i].size(), 0))
+            {
+                seterr(err, "carry driver: sending stems failed");
+                return rc;
+            }
+        return UMX_OK;
+    }
+    std::vector<float> sum_w((size_t)length, 0.0f), buf;
+    for (int t = 0; t < 4; ++t)
+        std::fill(out[t], out[t] + (size_t)2 * length, 0.0f);
+    for (int i = 0; i < nseg; ++i)
+    {
+        const int off = offsets[i], n = std::min(N, length - off);
+        const float *ws = mine[i].data();
+        if (i % world != 0)
+        {
+            buf.resize((size_t)4 * 2 * n);
+            if (int rc = p2p->recv(p2p->user, buf.data(), buf.size(), i % world))
+            {
+                seterr(err, "carry driver: receiving stems failed");
+                return rc;
+            }
+            ws = buf.data();
+        }
+        for (int k = 0; k < n; ++k)
+        {
+            for (int t = 0; t < 4; ++t)
+            {
+                out[t][2 * (size_t)(off + k)] += ws[((size_t)t * n + k) * 2];
+                out[t][2 * (size_t)(off + k) + 1] += ws[((size_t)t * n + k) * 2 + 1];
+            }
+            sum_w[off + k] += umx_transition_weight(k, n, N);
+        }
+    }
+    for (int t = 0; t < 4; ++t)
+        for (int k = 0; k < length; ++k)
+        {
+            out[t][2 * (size_t)k] /= sum_w[k];
+            out[t][2 * (size_t)k + 1] /= sum_w[k];
+        }
+    return UMX_OK;
+}

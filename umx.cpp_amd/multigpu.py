@@ -113,39 +113,77 @@ class EnginePhases:
 
 def separate_track_carry_mode(backend, wave, segment_samples, dist=None, rank=0, world=1, device="cpu"):
     """Exact split of one track over `world` ranks (state-carry wavefront); 4 x (2,L) on rank 0, else None.
-    `backend`: begin(chunk) / layer(l) / end() -> 4 x (2,n) / get_layer(l) / set_layer(l, a) / layer_floats()."""
+    `backend`: begin(chunk) / layer(l) / end() -> 4 x (2,n) / get_layer(l) / set_layer(l, a) / layer_floats().
+
+    A ctypes view of the C++17 host driver `umx_split_inference_carry` (include/umx_host.h, host/split.cpp): the
+    schedule, the weighting and the overlap-add live there; this function only adapts the backend object and a
+    torch.distributed point-to-point transport (gloo in the CPU tests) to its callback tables.  The device-resident
+    form of the same schedule -- RCCL send / recv on device pointers, no host bounce -- is host/mgpu.cpp."""
+    import ctypes as C
     import torch
+    from . import (P2P, P2P_FN, PH_BEGIN_FN, PH_END_FN, PH_LAYER_FN, PH_STATE_FN, PhasedBackend, HostError, host_lib, _fp)
     wave = np.asarray(wave, np.float32)
     L = wave.shape[1]
-    N = segment_samples
-    stride = int((1 - 0.25) * N)  # umx.cpp:181
-    offsets = list(range(0, L, stride))
-    nseg = len(offsets)
-    mine = [i for i in range(nseg) if i % world == rank]
     nf = backend.layer_floats()
-    local, pending = {}, []
-    for i in mine:
-        off = offsets[i]
-        n = min(N, L - off)
-        backend.begin(np.ascontiguousarray(wave[:, off:off + n]))
-        for l in range(3):
-            if i == 0:
-                backend.set_layer(l, np.zeros(nf, np.float32))  # create_lstm_data: zero state (lstm.cpp:82)
-            elif world > 1:
-                buf = torch.empty(nf, dtype=torch.float32, device=device)
-                dist.recv(buf, src=(i - 1) % world)
-                backend.set_layer(l, buf.cpu().numpy())
-            # world == 1: the state left by segment i-1 is already in place
-            backend.layer(l)
-            if world > 1 and i + 1 < nseg:
-                t = torch.from_numpy(backend.get_layer(l).copy()).to(device)
-                pending.append((dist.isend(t, dst=(i + 1) % world), t))
+    keep, failure = [], []
+
+    def guard(fn):
+        def wrapped(*a):
+            try:
+                r = fn(*a)
+                return 0 if r is None else r
+            except Exception as e:  # noqa: BLE001 - surfaced through the driver's error code
+                failure.append(e)
+                return 13
+        return wrapped
+
+    def _begin(_u, audio, n):
+        backend.begin(np.ascontiguousarray(np.ctypeslib.as_array(audio, shape=(n, 2)).T))
+        keep[:] = [n]
+
+    def _layer(_u, l):
+        backend.layer(l)
+
+    def _end(_u, out):
         stems = backend.end()
-        w = _weights(n, N)
-        local[i] = np.stack([np.asarray(s, np.float32) * w[None, :] for s in stems])
-    for req, _keep in pending:
+        n = keep[0]
+        for t in range(4):
+            np.ctypeslib.as_array(out[t], shape=(n, 2))[:, :] = np.asarray(stems[t], np.float32).T
+
+    def _get(_u, l, st):
+        np.ctypeslib.as_array(st, shape=(nf,))[:] = np.asarray(backend.get_layer(l), np.float32).ravel()
+
+    def _set(_u, l, st):
+        backend.set_layer(l, np.ctypeslib.as_array(st, shape=(nf,)).copy())
+
+    pending = []
+
+    def _send(_u, buf, n, dst):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,)).copy()).to(device)
+        pending.append((dist.isend(t, dst=dst), t))  # buffered: the driver may reuse `buf` at once
+
+    def _recv(_u, buf, n, src):
+        t = torch.empty(n, dtype=torch.float32, device=device)
+        dist.recv(t, src=src)
+        np.ctypeslib.as_array(buf, shape=(n,))[:] = t.cpu().numpy()
+
+    cbs = (PH_BEGIN_FN(guard(_begin)), PH_LAYER_FN(guard(_layer)), PH_END_FN(guard(_end)), PH_STATE_FN(guard(_get)),
+           PH_STATE_FN(guard(_set)), P2P_FN(guard(_send)), P2P_FN(guard(_recv)))
+    be = PhasedBackend(cbs[0], cbs[1], cbs[2], cbs[3], cbs[4], nf, None)
+    p2p = P2P(cbs[5], cbs[6], None)
+    a = np.ascontiguousarray(wave.T).ravel()
+    outs = [np.empty(2 * L, np.float32) for _ in range(4)] if rank == 0 else None
+    arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs]) if rank == 0 else None
+    err = C.create_string_buffer(256)
+    rc = host_lib().umx_split_inference_carry(C.byref(be), C.byref(p2p) if world > 1 else None, rank, world,
+                                              a.ctypes.data_as(_fp), L, segment_samples, arr, err)
+    for req, _t in pending:
         req.wait()
-    return _gather_overlap_add(local, mine, offsets, L, N, dist, rank, world, device)
+    if rc:
+        if failure:
+            raise failure[0]
+        raise HostError(rc, err.value.decode())
+    return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs] if rank == 0 else None
 
 
 def timed_region(step_fn, sync_fn, steps, warmup, dist=None, world=1, device=None):
