@@ -15,7 +15,9 @@ for v in variants:
         if v != "default":
             env["UMX_HIP_LIB"] = os.path.abspath(v)
         tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "")
-        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--lstm-profile", "--no-pcie", "--no-single-track"] + extra
+        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-single-track"] + extra
+        if os.environ.get("AB_PROFILE"):  # the in-kernel profiler slows the profiled workgroup, and with it its whole chain
+            cmd.append("--lstm-profile")
         if b == 1:
             cmd.append("--batched-lstm")
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)

@@ -118,7 +118,6 @@ struct Slot
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t rec_done[3] = {}; // LSTM layer l of this slot's segment has finished (state updated)
     bool have_times = false, last_persistent = false, used = false;
-    unsigned bepoch = 0; // batched LSTM launches on this slot's granule area since it was last cleared
 };
 } // namespace
 
@@ -1140,14 +1139,8 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
     if (persistent)
     {
-        // 4 tag bits of epoch, counted per slot (= per granule area): the area is zeroed whenever the count wraps, so
-        // between two clears no two launches on it share an epoch (a lane or chain that sat out some launches keeps
-        // its old granules, and they must never pass for a later launch's)
-        sl.bepoch = (sl.bepoch + 1) & 15u;
-        const bool clear = sl.bepoch == 0;
-        if (clear)
-            sl.bepoch = 1;
-        a.tag_epoch = sl.bepoch;
+        a.tag_epoch = next_tag_base() >> 12; // unique per launch (20 bits); the granule area is cleared when it wraps
+        const bool clear = tag_epoch == 0;
         a.t_begin = 0;
         a.t_end = T;
         a.census = 1;

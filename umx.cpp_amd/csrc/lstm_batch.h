@@ -17,10 +17,12 @@
 //       sum comes out of a fifth M tile whose A operand is all ones.  (The reference rounds q*scale+offset to fp32
 //       per weight first; the two differ by that rounding, ~1e-7 of the dot product, the size of one fp32 rounding
 //       of the sum itself.)
-//   B operand = h_{t-1}: N = track (lane & 15), K = hidden unit.  The producer publishes h ALREADY SPLIT: one
-//       8-byte granule per (unit, track) = {tag:16, h1:16, h2:16, h3:16} (h = h1 + h2 + h3 exactly, bf16 terms) --
-//       the same 8 bytes as lstm_kernels.h's {tag, fp32}, still one naturally aligned store that is its own flag,
-//       and the consumer feeds the matrix core without converting anything.  A lane fetches its B fragment (8 units of
+//   B operand = h_{t-1}: N = track (lane & 15), K = hidden unit.  The producer publishes h ALREADY SPLIT and already
+//       in fragment order: one 16-byte granule per (PAIR of units 2i, 2i+1; track) = {tag:32, h1 pair, h2 pair, h3 pair}
+//       (h = h1 + h2 + h3 exactly, bf16 terms; the two units of a pair sit in lanes 16 apart of the gate wave and meet
+//       through one ds_swizzle) -- 8 bytes per value like lstm_kernels.h's {tag, fp32}, still ONE naturally aligned
+//       store that is its own flag (16-byte stores are observed untorn on gfx950, MI355X_MICROARCH.md), and the three
+//       payload dwords of the consumer's i-th load ARE dword i of its three B fragments: no unpacking at all.  A lane fetches its B fragment (8 units of
 //       one track) with four 16-byte loads per K step, each of them contiguous across the wave (lstmb_granule_index).
 //   C = the 4 gates of unit 4*tile + (lane>>4) for track lane&15 sit in ONE lane (rows of the 16x16 result are
 //       4*(lane>>4)+reg): no cross-lane traffic in the gate phase.  The eight k-range partials meet through LDS
@@ -75,7 +77,7 @@ struct LstmBArgs
     int Hl, S, T, ldp, ldo, col0, layer, nchains;
     int tmap[4];
     int force_safe;
-    unsigned tag_epoch; // 4 bits used: a granule's tag is (epoch << 12) | (step + 1)
+    unsigned tag_epoch; // a granule's tag is (epoch << 12) | (step + 1): unique per launch (20 bits of epoch)
     unsigned lane_mask; // bit n = track lane n takes part in this launch
     int nbp;            // lanes the LDS arrays are sized for: power of two >= highest active lane + 1
     int bulk;           // W_ih-row ring: rows per bulk fetch (ring = 2 * bulk rows)
@@ -84,13 +86,20 @@ struct LstmBArgs
 };
 
 __host__ __device__ inline size_t lstmb_granule_words(int Hl) { return (size_t)2 * 8 * Hl * 16 * 2; } // 32-bit words
-// u64 index of the granule of (step parity slot, chain, hidden unit k, track n).  Within a K step (32 units) the order
-// is [pair of units i = (k%8)/2][8-unit group q = (k%32)/8][track][k%2]: the consumer's i-th 16-byte load is then
-// CONTIGUOUS across the wave (lane = q*16 + n), one L2 request per 128 B instead of one per 16 B, and the tracks of a
+// index (in 16-byte granules) of the granule holding hidden units (k & ~1, k | 1) of (step parity slot, chain, track n).
+// Within a K step (32 units) the order is [pair i = (k%8)/2][8-unit group q = (k%32)/8][track]: the consumer's i-th
+// 16-byte load is then CONTIGUOUS across the wave (lane = q*16 + n), one L2 request per 128 B, and the tracks of a
 // launch are packed (nbp), so small batches do not spread over sixteen times the lines.
 __host__ __device__ inline size_t lstmb_granule_index(int slot, int chain, int k, int n, int Hl, int nbp)
 {
-    return (((((size_t)(slot * 8 + chain) * (Hl / 32) + (k >> 5)) * 4 + ((k & 7) >> 1)) * 4 + ((k & 31) >> 3)) * nbp + n) * 2 + (k & 1);
+    return ((((size_t)(slot * 8 + chain) * (Hl / 32) + (k >> 5)) * 4 + ((k & 7) >> 1)) * 4 + ((k & 31) >> 3)) * nbp + n;
+}
+// 16-byte granule store through the granule area's buffer resource.  FAST (all parties share one XCD L2): plain
+// store; SAFE: write-through (sc0 sc1).
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+template <bool FAST> __device__ __forceinline__ void granule_store16(__amdgpu_buffer_rsrc_t rs, int byte_offset, uint4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, v), rs, byte_offset, 0, FAST ? 0 : 17);
 }
 __host__ __device__ inline size_t lstmb_lds_bytes(int nbp, int bulk)
 {
@@ -101,6 +110,17 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_b
 
 // sum of the NDW k-range partials in a fixed tree
 template <int NDW> __device__ __forceinline__ float tree_sum(const float (&p)[8])
+{
+    if (NDW == 8)
+        return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    if (NDW == 4)
+        return (p[0] + p[1]) + (p[2] + p[3]);
+    if (NDW == 2)
+        return p[0] + p[1];
+    return p[0];
+}
+
+template <int NDW> __device__ __forceinline__ float2v tree_sum2(const float2v (&p)[8])
 {
     if (NDW == 8)
         return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
@@ -186,7 +206,6 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
         hf[ks][2] = as_bf16x8(p3);
     }
 
-    gu64 *gran = (gu64 *)(a.sync + LSTM_SYNC_HEADER_WORDS);
     // the polls are 16-byte L1-bypassing buffer loads (buffer_load_dwordx4 ... sc1): two granules each
     const __amdgpu_buffer_rsrc_t gran_rs =
         __builtin_amdgcn_make_buffer_rsrc(a.sync + LSTM_SYNC_HEADER_WORDS, 0, (int)(lstmb_granule_words(HL) * 4), 0x00020000);
@@ -194,7 +213,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
     const float *const Pp = a.P[target] + ((size_t)dir * S + slice) * 64 + l;
     float *const outp = a.out[target] + (size_t)n * a.out_stride + a.col0 + dir * HL + unit;
     const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo, p_stride = a.p_stride;
-    const unsigned tag_hi = (a.tag_epoch & 15u) << 12;
+    const unsigned tag_hi = a.tag_epoch << 12;
     const int t_begin = a.t_begin, t_end = a.t_end;
 
     // W_ih x + b_ih rows: bulk fetch into the LDS ring (see lstm_kernels.h for why), rows x active lanes dealt to the
@@ -241,7 +260,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 int goff[KSW]; // byte offset of this lane's first 16 B (units 0,1 of its 8) inside the granule area
 #pragma unroll
                 for (int ks = 0; ks < KSW; ++ks)
-                    goff[ks] = (int)(lstmb_granule_index((step - 1) & 1, chain, (w * KSW + ks) * 32 + 8 * q, n, HL, nbp) * 8);
+                    goff[ks] = (int)(lstmb_granule_index((step - 1) & 1, chain, (w * KSW + ks) * 32 + 8 * q, n, HL, nbp) * 16);
                 if (FAST)
                 {
                     if (gate_wave)
@@ -269,8 +288,8 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
-                                bad |= (v[ks][i].x ^ want) | (v[ks][i].z ^ want);
-                        ok = (bad & 0xffffu) == 0;
+                                bad |= v[ks][i].x ^ want;
+                        ok = bad == 0;
                     }
                     if (prof && spins == 0)
                     {
@@ -291,23 +310,15 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                     __builtin_amdgcn_s_sleep(LSTMB_RETRY_SLEEP);
                 }
                 prof_spins = spins;
-                // granule = {lo: tag | h1 << 16, hi: h2 | h3 << 16}; a 16-byte load holds units (2i, 2i+1)
+                // granule i = {tag, h1 of units (2i, 2i+1), h2 pair, h3 pair}: the payload dwords are the fragments' dwords
 #pragma unroll
                 for (int ks = 0; ks < KSW; ++ks)
                 {
-                    uint4 p1, p2, p3;
-                    unsigned *d1 = &p1.x, *d2 = &p2.x, *d3 = &p3.x;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                    {
-                        const uint4 x = lane_on ? v[ks][i] : make_uint4(0u, 0u, 0u, 0u);
-                        d1[i] = (x.x >> 16) | (x.z & 0xffff0000u);
-                        d2[i] = (x.y & 0xffffu) | (x.w << 16);
-                        d3[i] = (x.y >> 16) | (x.w & 0xffff0000u);
-                    }
-                    hf[ks][0] = as_bf16x8(p1);
-                    hf[ks][1] = as_bf16x8(p2);
-                    hf[ks][2] = as_bf16x8(p3);
+                    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                    const uint4 g0 = lane_on ? v[ks][0] : z, g1 = lane_on ? v[ks][1] : z, g2 = lane_on ? v[ks][2] : z, g3 = lane_on ? v[ks][3] : z;
+                    hf[ks][0] = as_bf16x8(make_uint4(g0.y, g1.y, g2.y, g3.y));
+                    hf[ks][1] = as_bf16x8(make_uint4(g0.z, g1.z, g2.z, g3.z));
+                    hf[ks][2] = as_bf16x8(make_uint4(g0.w, g1.w, g2.w, g3.w));
                 }
                 // every gate wave of this workgroup is past iteration step - 2 (it has crossed the barrier of step - 1),
                 // so ring rows <= step - 2 may be replaced: rows [step-1+bulk, step-1+2 bulk) take the slots of
@@ -380,17 +391,17 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 #if LSTM_GATE_PRIO
             __builtin_amdgcn_s_setprio(LSTM_GATE_PRIO);
 #endif
-            float px[8], py[8], pz[8], pw_[8];
+            // the NDW k-range partials, summed in a fixed tree, two gates per (unswizzled) packed add
+            float2v pa[8], pb[8];
 #pragma unroll
             for (int ww = 0; ww < NDW; ++ww)
             {
                 const float4 v4 = part[((size_t)((((step & 1) * 8 + ww) * 4 + w) * 4) + q) * nbp + n];
-                px[ww] = v4.x;
-                py[ww] = v4.y;
-                pz[ww] = v4.z;
-                pw_[ww] = v4.w;
+                pa[ww] = float2v{v4.x, v4.y};
+                pb[ww] = float2v{v4.z, v4.w};
             }
-            const float s0 = tree_sum<NDW>(px), s1 = tree_sum<NDW>(py), s2 = tree_sum<NDW>(pz), s3 = tree_sum<NDW>(pw_);
+            const float2v sa = tree_sum2<NDW>(pa), sb = tree_sum2<NDW>(pb);
+            const float s0 = sa.x, s1 = sa.y, s2 = sb.x, s3 = sb.y;
             // ((W_ih x + b_ih) + W_hh h) + b_hh, lstm.cpp:132-140
             const float pre_i = (p4.x + s0) + bh.x, pre_f = (p4.y + s1) + bh.y, pre_g = (p4.z + s2) + bh.z, pre_o = (p4.w + s3) + bh.w;
             float i_t, f_t, g_t, o_t;
@@ -410,19 +421,25 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             }
             const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
             const float h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
+            // h split in three bf16 terms; the odd unit of the pair sits 16 lanes up in this wave
+            const unsigned b1 = cvt_pk_bf16(h, 0.f) & 0xffffu;
+            const float r1 = h - __uint_as_float(b1 << 16);
+            const unsigned b2 = cvt_pk_bf16(r1, 0.f) & 0xffffu;
+            const float r2 = r1 - __uint_as_float(b2 << 16);
+            const unsigned b3 = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+            const unsigned mine12 = b1 | (b2 << 16);
+            const unsigned other12 = (unsigned)__builtin_amdgcn_ds_swizzle((int)mine12, 0x401F); // lane ^ 16
+            const unsigned other3 = (unsigned)__builtin_amdgcn_ds_swizzle((int)b3, 0x401F);
             if (lane_on)
             {
                 c = c_t;
                 hlast = h;
-                // publish h split in three bf16 terms, tagged step + 1
-                const unsigned b1 = cvt_pk_bf16(h, 0.f) & 0xffffu;
-                const float r1 = h - __uint_as_float(b1 << 16);
-                const unsigned b2 = cvt_pk_bf16(r1, 0.f) & 0xffffu;
-                const float r2 = r1 - __uint_as_float(b2 << 16);
-                const unsigned b3 = cvt_pk_bf16(r2, 0.f) & 0xffffu;
-                const unsigned long long gv = (unsigned long long)(tag_hi | (unsigned)(step + 1) | (b1 << 16)) |
-                                              ((unsigned long long)(b2 | (b3 << 16)) << 32);
-                granule_store<FAST>(gran + lstmb_granule_index(step & 1, chain, unit, n, HL, nbp), gv);
+                if ((q & 1) == 0) // publish the pair (this unit, the next), tagged step + 1
+                {
+                    const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u),
+                                                b3 | (other3 << 16));
+                    granule_store16<FAST>(gran_rs, (int)(lstmb_granule_index(step & 1, chain, unit, n, HL, nbp) * 16), gv);
+                }
 #if !LSTMB_DEFER_OUT
                 outp[(size_t)t * ldo] = h; // lstm.cpp:163-164,170-171
 #endif
