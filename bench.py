@@ -137,8 +137,9 @@ def main():
                          "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
     ap.add_argument("--mode", choices=["segments", "track"], default="segments",
                     help="track: ONE 600 s track, its segments sharded over the ranks with exact LSTM state carry (config 4)")
-    ap.add_argument("--gemm", choices=["bf16x3", "f32"], default=None,
-                    help="dense-stack GEMM flavour: bf16x3 (default; three-term bf16 split, fp32-class accuracy) or f32 MFMA")
+    ap.add_argument("--gemm", choices=["planes", "bf16x3", "f32"], default=None,
+                    help="dense-stack GEMM flavour: planes (default; bf16 matrix cores, pre-split operands, fp32-class accuracy), "
+                         "bf16x3 (the same arithmetic, operands split while staged) or f32 MFMA")
     ap.add_argument("--expanded-weights", action="store_true",
                     help="expand the u8/u16 weights at load time (fp32 / three bf16 planes in HBM) instead of keeping "
                          "them quantised in HBM with dequantisation inside the kernels (the default, BASELINE config 5)")
@@ -285,8 +286,7 @@ def main():
         seg_sec = N / 44100.0
         value = world * B * args.steps * seg_sec / dt
         gemm, rec, byt = algorithmic_work(T, H)
-        flavour = args.gemm or os.environ.get("UMX_GEMM", "bf16x3")
-        u8x = flavour == "bf16x3" and not args.expanded_weights and not args.u8_dequant  # u8 weights as exact bf16 integers
+        flavour = args.gemm or os.environ.get("UMX_GEMM", "planes")
         traffic_src = args.traffic_csv or next(iter(sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_fetch_write_per_kernel.csv")),
                                                            reverse=True)), None)
         traffic = read_traffic(traffic_src) if traffic_src else {}
@@ -303,8 +303,8 @@ def main():
             ms = sum(stage_ms.get(kk, 0.0) for kk in stage_keys) / launches
             ms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in stage_keys) / launches
             alg = gemm[work_key]
-            issued = alg * products if flavour == "bf16x3" else alg
-            peak = BF16_MFMA_PEAK_TF if flavour == "bf16x3" else F32_MFMA_PEAK_TF
+            issued = alg * products if flavour != "f32" else alg
+            peak = BF16_MFMA_PEAK_TF if flavour != "f32" else F32_MFMA_PEAK_TF
             ach = issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"kernel": name, "bound": "mfma", "launches_per_step": launches, "launch_ms": round(ms, 4),
                     "launch_ms_alone": round(ms_alone, 4), "algorithmic_flops_per_launch": alg,
@@ -312,12 +312,15 @@ def main():
                     "frac": round(ach / peak, 4), "frac_alone": round(issued / (ms_alone * 1e-3) / 1e12 / peak, 4) if ms_alone > 0 else None,
                     "algorithmic_TFLOPs_alone": round(alg / (ms_alone * 1e-3) / 1e12, 1) if ms_alone > 0 else None,
                     "traffic": find_traffic(*tneedles)}
-        gname = "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel"
-        p8 = 3 if u8x else 6
+        planes = flavour in ("planes", "bf16x3")  # both run on the bf16 matrix cores
+        gname = "gemm_planes_kernel" if flavour == "planes" else "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel"
+        exact = planes and not args.expanded_weights and not args.u8_dequant  # integer weights as exact bf16 terms
+        p8 = 3 if exact else 6
+        p16 = 5 if (exact and flavour == "planes") else 6
         kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gname}<G_FC1>", (gname, "ILi0E")),
                    gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gname}<G_IH>", (gname, "ILi1E")),
-                   gemm_entry(["fc2"], "fc2", 6, f"{gname}<G_FC2>", (gname, "ILi2E")),
-                   gemm_entry(["fc3_mask"], "fc3_mask", 6, f"{gname}<G_FC3>", (gname, "ILi3E"))]
+                   gemm_entry(["fc2"], "fc2", p16, f"{gname}<G_FC2>", (gname, "ILi2E")),
+                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{gname}<G_FC3>", (gname, "ILi3E"))]
         lstm_keys = [f"lstm_rec{l}" for l in range(3)]
         lms = sum(stage_ms.get(kk, 0.0) for kk in lstm_keys) / 3
         lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3
@@ -390,9 +393,11 @@ def main():
                        "audio_seconds_per_step": B * seg_sec,
                        "lstm_kernel": ("batched, matrix cores (lstm_batch_kernel)" if batched else "single-track, VALU (lstm_persistent_kernel)"),
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
-                       "gemm": (flavour + (" (fp32 activations split into 3 bf16 terms, f32 accumulate; u8 weights exact in one bf16 term "
-                                           "(3 products), u16 / fp32 weights split in three (6 products): error below fp32 rounding)"
-                                           if flavour == "bf16x3" else " MFMA")),
+                       "gemm": (flavour + (" (bf16 matrix cores, f32 accumulate: activations split once into 3 bf16 planes, u8 weights exact in "
+                                           "1 plane (3 products), u16 weights exact in 2 planes (5 products), LDS-DMA staging, 256x256 tiles "
+                                           "over all track lanes)" if flavour == "planes" else
+                                           " (fp32 operands split into 3 bf16 terms while staged, 3 / 6 products)" if flavour == "bf16x3"
+                                           else " MFMA")),
                        "weights_resident": ("expanded at load (f32 / bf16 planes)" if args.expanded_weights
                                             else "u8/u16 as in the file (BASELINE config 5)"),
                        "weight_bytes": weight_bytes,

@@ -1,11 +1,19 @@
-"""tools/gemm_accuracy.py -- how far is each GEMM flavour from the exact result?
-fc1 -> bn1 -> tanh of one segment (hidden 1024, K = 2974) evaluated in float64 with numpy from the engine's own
-input tap and the dequantised weights, against: the fp32-MFMA kernel, the bf16x3 kernel, the CPU oracle (fp32)."""
+"""tools/gemm_accuracy.py -- how far is each arithmetic flavour from the exact result?  (The bench line says dtype "f32":
+this is the evidence that the bf16-split matrix-core paths are no less accurate than fp32 arithmetic.)
+
+Evaluated in float64 from the engine's OWN taps (so that only the stage under test contributes) and the weights the
+reference would use (fl(q*scale+offset), model.cpp:610-616):
+  fc1 -> bn1 -> tanh       K = 2974, u8 weights      [planes: exact one-plane weights, 3 products, affine map on the sum]
+  fc2 -> bn2 -> relu       K = 2048, u16 weights     [planes: exact two-plane weights, 5 products]
+  3-layer BiLSTM           2584-step-class recurrence, u8 W_hh, from the engine's fc1 output (torch float64 LSTM)
+for the GEMM flavours planes / bf16x3 (staged split) / f32 MFMA, the single-track (VALU) and the batched (matrix-core)
+LSTM kernels, and the CPU oracle (fp32)."""
 import sys
 import tempfile
 from pathlib import Path
 
 import numpy as np
+import torch
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
@@ -20,28 +28,64 @@ hidden, targets = pkg.ggml.read_model(path)
 wave = pkg.ggml.synth_audio(N, 321)
 om = po.Model.load(path)
 ref_out, taps = po.umx_inference(om, wave, n_buf=N, want_taps=True)
-res = {}
-for name, bx in (("f32 MFMA", False), ("bf16x3 MFMA", True)):
-    eng = pkg.Engine.from_file(path, N, gemm="bf16x3" if bx else "f32")
-    eng.infer_segment(wave, pkg.FLAG_DEBUG_TAPS)
-    res[name] = ([eng.tap("fc1", t) for t in range(4)], eng.tap("x")[:, :2 * pkg.CROP].astype(np.float64),
-                 [eng.tap("mask", t) for t in range(4)])
+T = N // 1024 + 1
+
+
+def run(**kw):
+    eng = pkg.Engine.from_file(path, N, **kw)
+    if kw.get("tracks", 1) > 1:
+        eng.infer_batch([wave] * kw["tracks"], pkg.FLAG_DEBUG_TAPS)
+    else:
+        eng.infer_segment(wave, pkg.FLAG_DEBUG_TAPS)
+    r = {k: [eng.tap(k, t) for t in range(4)] for k in ("fc1", "lstm", "fc2", "mask")}
+    r["x"] = eng.tap("x")[:, :2 * pkg.CROP].astype(np.float64)
     eng.close()
-x64 = res["f32 MFMA"][1]
-print(f"{'target':6s} {'flavour':12s} {'max abs err':>12s} {'rel L2 err':>12s}   (fc1/bn1/tanh output vs float64)")
-for t in range(4):
-    tt = targets[t]
-    g = lambda n: tt[n]["f32"].astype(np.float64)
-    sc = np.tile(g("input_scale"), 2)
-    mn = np.tile(g("input_mean"), 2)
-    a = x64 * sc + mn
-    y = a @ g("fc1.weight").reshape(H, -1).T
-    y = (y - g("bn1.running_mean")) / np.sqrt(g("bn1.running_var") + 1e-5) * g("bn1.weight") + g("bn1.bias")
-    y = np.tanh(y)
-    for name in ("f32 MFMA", "bf16x3 MFMA"):
-        e = res[name][0][t].astype(np.float64) - y
-        print(f"{t:<6d} {name:12s} {np.abs(e).max():12.3e} {np.linalg.norm(e) / np.linalg.norm(y):12.3e}")
-    e = taps["fc1_out"][t].astype(np.float64) - y
-    print(f"{t:<6d} {'CPU oracle':12s} {np.abs(e).max():12.3e} {np.linalg.norm(e) / np.linalg.norm(y):12.3e}")
-print("end-to-end mask, bf16x3 vs f32 MFMA: max abs",
-      max(float(np.abs(res['bf16x3 MFMA'][2][t] - res['f32 MFMA'][2][t]).max()) for t in range(4)))
+    return r
+
+
+res = {"planes": run(gemm="planes"), "bf16x3": run(gemm="bf16x3"), "f32 MFMA": run(gemm="f32"),
+       "planes+batched LSTM": run(gemm="planes", tracks=2)}
+oracle = {"fc1": taps["fc1_out"], "lstm": taps["lstm_out"], "fc2": taps["fc2_out"]}
+
+
+def g(t, n):
+    return targets[t][n]["f32"].astype(np.float64)
+
+
+def bn(y, t, name):
+    return (y - g(t, name + ".running_mean")) / np.sqrt(g(t, name + ".running_var") + 1e-5) * g(t, name + ".weight") + g(t, name + ".bias")
+
+
+def report(stage, name, got, want):
+    e = got.astype(np.float64) - want
+    print(f"{stage:6s} {name:22s} max abs {np.abs(e).max():10.3e}   rel L2 {np.linalg.norm(e) / np.linalg.norm(want):10.3e}")
+
+
+for t in (0, 3):
+    print(f"--- target {t}")
+    for name, r in res.items():
+        if "batched" in name:
+            continue
+        a = r["x"] * np.tile(g(t, "input_scale"), 2) + np.tile(g(t, "input_mean"), 2)
+        y = np.tanh(bn(a @ g(t, "fc1.weight").reshape(H, -1).T, t, "bn1"))
+        report("fc1", name, r["fc1"][t], y)
+    a = res["planes"]["x"] * np.tile(g(t, "input_scale"), 2) + np.tile(g(t, "input_mean"), 2)
+    report("fc1", "CPU oracle (fp32)", oracle["fc1"][t], np.tanh(bn(a @ g(t, "fc1.weight").reshape(H, -1).T, t, "bn1")))
+    for name, r in res.items():  # fc2 from the engine's own [fc1 | lstm]
+        cat = np.concatenate([r["fc1"][t], r["lstm"][t]], axis=1).astype(np.float64)
+        y = np.maximum(bn(cat @ g(t, "fc2.weight").reshape(H, -1).T, t, "bn2"), 0)
+        report("fc2", name, r["fc2"][t], y)
+    cat = np.concatenate([oracle["fc1"][t], oracle["lstm"][t]], axis=1).astype(np.float64)
+    report("fc2", "CPU oracle (fp32)", oracle["fc2"][t], np.maximum(bn(cat @ g(t, "fc2.weight").reshape(H, -1).T, t, "bn2"), 0))
+    # the recurrence in float64 from each engine's own fc1 output (zero initial state)
+    lstm = torch.nn.LSTM(H, H // 2, num_layers=3, bidirectional=True).double()
+    lstm.load_state_dict({f"{wn}_l{l}{sfx}": torch.from_numpy(g(t, f"lstm.{wn}_l{l}{sfx}").reshape(targets[t][f"lstm.{wn}_l{l}{sfx}"]["f32"].shape))
+                          for l in range(3) for sfx in ("", "_reverse") for wn in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")})
+    with torch.no_grad():
+        for name in ("planes", "planes+batched LSTM", "f32 MFMA"):
+            want = lstm(torch.from_numpy(res[name]["fc1"][t].astype(np.float64))[:, None, :])[0][:, 0].numpy()
+            report("lstm", name + (" (VALU kernel)" if name == "planes" else ""), res[name]["lstm"][t], want)
+        want = lstm(torch.from_numpy(oracle["fc1"][t].astype(np.float64))[:, None, :])[0][:, 0].numpy()
+        report("lstm", "CPU oracle (fp32)", oracle["lstm"][t], want)
+print("end-to-end mask, planes vs f32 MFMA: max abs",
+      max(float(np.abs(res['planes']['mask'][t] - res['f32 MFMA']['mask'][t]).max()) for t in range(4)))

@@ -14,7 +14,8 @@
 //         sum_k a_k (q_k s + o) = s sum_k a_k (q_k - c) + (o + c s) sum_k a_k,   c = 128 or 32896
 //   * tiles go global -> LDS by `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write, no VALU), 16 bytes per lane,
 //     the XOR swizzle of the LDS layout folded into WHICH 16 bytes a lane fetches;
-//   * products per 32x32x16 block: 3 (u8), 6 (u16: a3 * low plane included) or 6 (fp32), fp32 accumulate.
+//   * products per 32x32x16 block: 3 (u8), 5 (u16: a3 x low plane, <= 2^-25 of the leading term, is dropped) or 6
+//     (fp32: the bf16x3 rule of gemm_bf16x3.h), fp32 accumulate.
 // Block tile (64 WM) x (64 WN) x 32, WM x WN waves, each 2 x 2 MFMA tiles of v_mfma_f32_32x32x16_bf16.  With three
 // planes per activation the kernel is bound by the bytes it pulls out of the L2s (128 x 128 tiles measured 6.5-10 TB/s
 // of L2 -> LDS traffic at 25-40 % of the matrix peak), so the default tile is 256 x 256 (16 waves, one workgroup per CU:
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
             {                                                                                                        \
                 GP_TERM(2, 0, kk) GP_TERM(1, 0, kk) GP_TERM(0, 0, kk)                                                \
             }                                                                                                        \
-            else if (NBP == 2) /* B = P_hi + P_lo (both exact): a3 P_lo, a2 P_lo, a3 P_hi, a1 P_lo, a2 P_hi, a1 P_hi */ \
-            {                                                                                                        \
-                GP_TERM(2, 1, kk) GP_TERM(1, 1, kk) GP_TERM(2, 0, kk) GP_TERM(0, 1, kk) GP_TERM(1, 0, kk) GP_TERM(0, 0, kk) \
+            else if (NBP == 2) /* B = P_hi + P_lo (both exact): a2 P_lo, a3 P_hi, a1 P_lo, a2 P_hi, a1 P_hi; dropped: */ \
+            {                                  /* a3 P_lo <= 2^-17 |a| * 2^7 = 2^-25 of the largest term |a| * 2^15 */ \
+                GP_TERM(1, 1, kk) GP_TERM(2, 0, kk) GP_TERM(0, 1, kk) GP_TERM(1, 0, kk) GP_TERM(0, 0, kk)            \
             }                                                                                                        \
             else                                                                                                     \
             {                                                                                                        \
