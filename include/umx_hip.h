@@ -43,6 +43,8 @@ extern "C" {
 #define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the mask tap (T x 4098 per target) for umx_hip_read_tap */
 #define UMX_FLAG_LSTM_FORCE_SAFE 0x40 /* persistent kernel: never take the intra-XCD fast protocol */
 #define UMX_FLAG_LSTM_PROFILE 0x80  /* persistent kernel: record per-phase cycle counters */
+#define UMX_FLAG_DEBUG_LSTM_ABORT 0x2000 /* testing: the persistent LSTM launch of layer 1 gives up half way, exactly as if a
+                                          hidden-state poll had timed out (exercises the recovery of umx_hip_sync) */
 #define UMX_FLAG_PRECISE_ACT 0x1000 /* LSTM gates with the device-library expf/tanhf + IEEE division instead of
                                        the hardware v_exp_f32 / v_rcp_f32 forms (~1e-7 abs difference) */
 
@@ -160,8 +162,15 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
                               float *const *out_host, unsigned flags);
 int umx_hip_infer_batch_device(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_dev, const int *n,
                                float *const *out_dev, unsigned flags);
-int umx_hip_sync(umx_hip_ctx *ctx); /* waits for everything queued; also surfaces a persistent-kernel timeout as
-                                       UMX_ERR_TIMEOUT (the streaming state of every lane is then reset to zero) */
+/* Waits for everything queued.  A persistent LSTM launch needs its whole grid co-resident; inside a process that is
+ * guaranteed (launches of all contexts on a device pass one admission gate), but another PROCESS on the same GPU can
+ * still occupy the CUs, in which case the launch gives up after a bounded spin instead of hanging.  umx_hip_sync then
+ * RECOVERS: the stream state of every lane is restored to what it was before the first segment queued since the last
+ * sync (a per-layer copy is kept for up to 8 queued calls), those segments are run again with the per-step driver
+ * (bit-identical), and later calls of this context use that driver.  UMX_OK after a recovery; umx_hip_last_error then
+ * starts with "recovered".  UMX_ERR_TIMEOUT (streaming state reset to zero) only when recovery is impossible: more
+ * than 8 calls were queued, or the caller's device buffers of those calls are gone. */
+int umx_hip_sync(umx_hip_ctx *ctx);
 /* hip_stream = a hipStream_t of the caller.  order_after: everything queued by LATER calls on this context starts
  * only after what is on hip_stream now.  order_before: hip_stream waits for everything queued on the context so far. */
 int umx_hip_order_after(umx_hip_ctx *ctx, void *hip_stream);
@@ -181,6 +190,15 @@ int umx_hip_split_inference(umx_hip_ctx *ctx, const float *audio_host, int lengt
                             unsigned flags, void (*progress)(float, void *), void *progress_user);
 int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int length, int offset, float *const out_host[4],
                             unsigned flags, void (*progress)(float, void *), void *progress_user);
+
+/* The same for n_tracks tracks at once, one per track lane of a context made by umx_hip_create_tracks: call s of the
+ * segment loop runs segment s of EVERY track that still has one (their LSTM recurrences share one launch per layer),
+ * a finished track's lane sits idle.  audio_host[i] (2,length[i]), out_host[4*i + t] (2,length[i]); shift_offset[i] < 0:
+ * split_inference, >= 0: shift_inference with that offset.  Track i's stems are bit-identical to running it alone on a
+ * context with the batched LSTM kernel. */
+int umx_hip_separate_tracks(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *length,
+                            const int *shift_offset, float *const *out_host, unsigned flags, void (*progress)(float, void *),
+                            void *progress_user);
 
 /* One segment phase by phase: front (STFT, fc1, W_ih layer 0) | LSTM layer 0 | 1 | 2 | back (fc2, fc3, Wiener,
  * iSTFT).  Same kernels and results as umx_hip_infer_segment; the cuts are where the reference's per-chain

@@ -129,3 +129,44 @@ def test_idle_lane_keeps_its_state_and_lanes_reset_independently(pkg, model_smal
     eng.close()
     with pytest.raises(RuntimeError):
         pkg.Engine(targets, 128, N, tracks=17)
+
+
+def test_whole_tracks_as_track_lanes_and_the_batch_cli(pkg, po, tmp_path):
+    """umx_hip_separate_tracks: tracks of different lengths through one context, their segments in lock step (a finished
+    track's lane idles): every track equals what it gets alone on a batched-kernel context (bitwise) and the oracle's
+    shift_inference (tolerance); then the same through `umx-batch` on wav files."""
+    import subprocess
+    from pathlib import Path
+    H, N = 128, 16 * 1024
+    path = str(tmp_path / "m.bin.gz")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=17), H)
+    om = po.Model.load(path)
+    lens = [int(N * 3.4), N // 2, int(N * 1.9)]
+    waves = [pkg.ggml.synth_audio(L, 40 + i) for i, L in enumerate(lens)]
+    offs = [4033, None, 700]
+    eng = pkg.Engine.from_file(path, N, tracks=3)
+    got = eng.separate_many(waves, shift_offsets=offs)
+    eng.close()
+    one = pkg.Engine.from_file(path, N, lstm_batched=True)
+    for i in range(3):
+        alone = one.separate(waves[i], shift_offset=offs[i])
+        ref = po.shift_inference(om, waves[i], N, offs[i]) if offs[i] is not None else po.split_inference(om, waves[i], N)
+        for t in range(4):
+            assert (got[i][t] == alone[t]).all(), (i, t)
+            assert np.abs(got[i][t] - ref[t]).max() < TOL_WAVE, (i, t)
+    one.close()
+    # the files form: production segment size, the reference's shipped 5.94 s tracks
+    gold = Path(__file__).parent / "golden"
+    out = tmp_path / "out"
+    cli = Path(pkg.HERE) / "umx-batch"
+    r = subprocess.run([str(cli), path, str(out), str(gold / "gspi_stereo.wav"), str(gold / "gspi_mono.wav")], capture_output=True, text=True,
+                       env={**__import__("os").environ, "UMX_SHIFT_OFFSET": "4033"}, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for name in ("gspi_stereo", "gspi_mono"):
+        wave, _ = pkg.wav_load(gold / f"{name}.wav")
+        ref = po.shift_inference(om, wave, pkg.SEGMENT_SAMPLES, 4033)
+        for t in range(4):
+            g, ch = pkg.wav_load(out / name / f"target_{t}.wav")
+            assert ch == 2 and np.abs(g - ref[t]).max() < TOL_WAVE, (name, t)
+    bad = subprocess.run([str(cli), path], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Usage" in bad.stderr

@@ -28,6 +28,7 @@ FLAG_DEBUG_TAPS = 0x20
 FLAG_LSTM_FORCE_SAFE = 0x40
 FLAG_LSTM_PROFILE = 0x80
 FLAG_PRECISE_ACT = 0x1000
+FLAG_DEBUG_LSTM_ABORT = 0x2000
 
 
 def FLAG_SKIP_TARGET(t):
@@ -87,6 +88,8 @@ def hip_lib():
     lib.umx_hip_infer_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.c_uint]
     lib.umx_hip_infer_batch_async.argtypes = lib.umx_hip_infer_batch.argtypes
     lib.umx_hip_infer_batch_device.argtypes = lib.umx_hip_infer_batch.argtypes
+    lib.umx_hip_separate_tracks.argtypes = [C.c_void_p, C.c_int, C.POINTER(_fp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_fp),
+                                            C.c_uint, C.c_void_p, C.c_void_p]
     lib.umx_hip_order_after.argtypes = [C.c_void_p, C.c_void_p]
     lib.umx_hip_order_before.argtypes = [C.c_void_p, C.c_void_p]
     lib.umx_hip_weight_bytes.restype = C.c_size_t
@@ -141,7 +144,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_track_stream_reset", "umx_hip_track_stream_get", "umx_hip_track_stream_set",
                "umx_hip_infer_segment_async", "umx_hip_infer_batch", "umx_hip_infer_batch_async",
                "umx_hip_infer_batch_device", "umx_hip_order_after", "umx_hip_order_before",
-               "umx_hip_phase_stream", "umx_hip_stream_state_device", "umx_hip_segment_begin_device", "umx_hip_segment_end_device",
+               "umx_hip_separate_tracks", "umx_hip_phase_stream", "umx_hip_stream_state_device", "umx_hip_segment_begin_device", "umx_hip_segment_end_device",
                "umx_hip_weight_stems_device", "umx_hip_track_accumulate_device", "umx_hip_track_normalise_device", "umx_hip_weight_bytes", "umx_hip_destroy", "umx_hip_last_error", "umx_hip_stream_floats",
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
@@ -304,6 +307,18 @@ class Engine:
         self.separate_interleaved(a, L, outs, flags, shift_offset)
         return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs]
 
+    def separate_many(self, waves, flags=0, shift_offsets=None):
+        """Several tracks at once, one per track lane (umx_hip_separate_tracks): list of (2,L_i) -> list of [4 x (2,L_i)]."""
+        nt = len(waves)
+        ins = [np.ascontiguousarray(np.asarray(w, np.float32).T).ravel() for w in waves]
+        Ls = [np.asarray(w).shape[1] for w in waves]
+        outs = [[np.empty(2 * L, np.float32) for _ in range(4)] for L in Ls]
+        a = (_fp * nt)(*[x.ctypes.data_as(_fp) for x in ins])
+        o = (_fp * (4 * nt))(*[x.ctypes.data_as(_fp) for t4 in outs for x in t4])
+        sh = (C.c_int * nt)(*[(-1 if s is None else s) for s in (shift_offsets or [None] * nt)])
+        self._check(self.lib.umx_hip_separate_tracks(self.h, nt, a, (C.c_int * nt)(*Ls), sh, o, flags, None, None))
+        return [[np.ascontiguousarray(x.reshape(L, 2).T) for x in t4] for t4, L in zip(outs, Ls)]
+
     def separate_interleaved(self, a, L, outs, flags=0, shift_offset=None):
         """The bare C call: a = (2,L) interleaved float32, outs = 4 preallocated float32[2L]; returns seconds."""
         import time
@@ -372,6 +387,9 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.umx_hip_sync(self.h))
+
+    def last_error(self):
+        return self.lib.umx_hip_last_error(self.h).decode()
 
     def lstm_was_persistent(self):
         return bool(self.lib.umx_hip_lstm_was_persistent(self.h))

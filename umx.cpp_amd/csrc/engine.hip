@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -121,6 +122,64 @@ struct Slot
 };
 } // namespace
 
+// Admission of persistent LSTM grids, process-wide and per device.  A persistent launch needs ALL its workgroups
+// co-resident (they exchange granules), so two such grids may only be in flight together if both fit the device.
+// Inside one context the pipeline orders its own launches with events; this gate does the same ACROSS contexts
+// (several engines on one GPU, driven from several threads): a launch that would not fit is made to wait -- on the
+// device, through a stream-wait on the oldest admitted grid's completion event, never by blocking the host.
+// Units are half CUs: a single-track workgroup (two fit a CU) counts 1, a batched one (one per CU) counts 2.
+namespace
+{
+struct LstmGate
+{
+    std::mutex m;
+    struct Grid
+    {
+        hipEvent_t done;
+        int units;
+    };
+    std::vector<Grid> inflight;
+    std::vector<hipEvent_t> pool;
+};
+LstmGate g_gate[16];
+
+// admit + launch + record under the gate's lock (an event that has not been recorded yet would read as complete)
+template <class Launch> hipError_t lstm_gate_launch(int device, hipStream_t st, int units, int capacity_units, Launch launch)
+{
+    LstmGate &g = g_gate[device & 15];
+    std::lock_guard<std::mutex> lock(g.m);
+    int used = 0;
+    for (size_t i = 0; i < g.inflight.size();)
+        if (hipEventQuery(g.inflight[i].done) == hipSuccess)
+        {
+            g.pool.push_back(g.inflight[i].done);
+            g.inflight.erase(g.inflight.begin() + i);
+        }
+        else
+            used += g.inflight[i++].units;
+    (void)hipGetLastError(); // hipEventQuery reports "not ready" as an error
+    for (size_t i = 0; i < g.inflight.size() && used + units > capacity_units; ++i)
+    {
+        (void)hipStreamWaitEvent(st, g.inflight[i].done, 0); // oldest first; it has left the device when we start
+        used -= g.inflight[i].units;
+    }
+    hipEvent_t ev = nullptr;
+    if (!g.pool.empty())
+    {
+        ev = g.pool.back();
+        g.pool.pop_back();
+    }
+    else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+        ev = nullptr;
+    const hipError_t e = launch();
+    if (ev && e == hipSuccess && hipEventRecord(ev, st) == hipSuccess)
+        g.inflight.push_back({ev, units});
+    else if (ev)
+        g.pool.push_back(ev);
+    return e;
+}
+} // namespace
+
 // kernel instantiation pickers
 static const void *lstm_persistent_fn(int kpw, bool precise)
 {
@@ -184,6 +243,22 @@ struct umx_hip_ctx
     long long nseg = 0;       // segments queued since creation
     size_t lsync_words = 0;
     bool persistent_ok = true;
+    int n_cus = 256;
+    // what umx_hip_sync needs to redo the calls queued since the last sync after a persistent-kernel timeout
+    struct PendingCall
+    {
+        int nb;
+        const float *audio[LSTMB_MAX_TRACKS];
+        int n[LSTMB_MAX_TRACKS];
+        float *out[4 * LSTMB_MAX_TRACKS];
+        float *host_out[4 * LSTMB_MAX_TRACKS]; // host-pointer entry points: where the stems are copied afterwards
+        unsigned flags;
+    };
+    static constexpr int kBackupCalls = 8;
+    std::vector<PendingCall> pending;
+    float *backup = nullptr; // [kBackupCalls][3 layers][B * state_floats]: the stream state right before each layer launch
+    bool no_recovery = false, recovering = false;
+    int recover();
     int lstm_threads = LSTM_THREADS; // 512 (two workgroups per CU fit) or 576 (dedicated gate wave)
     int lstm_capacity = 0;           // workgroups of the persistent LSTM kernel that can be co-resident
     unsigned last_flags = 0;
@@ -232,8 +307,16 @@ struct umx_hip_ctx
     // whole track on the device (split_inference / shift_inference, umx.cpp:99-295)
     int track(const float *audio_host, int length, int shift_offset, float *const out_host[4], unsigned flags,
               void (*progress)(float, void *), void *progress_user);
-    float *trk_in = nullptr, *trk_out[4] = {}, *trk_sumw = nullptr, *trk_seg[2][4] = {};
-    size_t trk_cap = 0; // samples the track buffers hold
+    int tracks(int nt, const float *const *audio_host, const int *length, const int *shift_offset, float *const *out_host, unsigned flags,
+               void (*progress)(float, void *), void *progress_user);
+    int tracks_once(int nt, const float *const *audio_host, const int *length, const int *shift_offset, float *const *out_host,
+                    unsigned flags, void (*progress)(float, void *), void *progress_user);
+    struct TrackBufs // whole-track driver, per track lane: the (shifted) track, 4 stem accumulators, weight sum, 2 x 4 segment stems
+    {
+        float *in = nullptr, *out[4] = {}, *sumw = nullptr, *seg[2][4] = {};
+        size_t cap = 0;
+    };
+    std::vector<TrackBufs> trk;
     hipEvent_t trk_acc_ev[2] = {};
     int phase_begin(const float *audio_host, int n, unsigned flags);
     int phase_begin_device(const float *audio_dev, int n, unsigned flags);
@@ -789,6 +872,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             return rc;
     if (int rc = dalloc(&state, state_floats() * B))
         return rc;
+    if (int rc = dalloc(&backup, (size_t)kBackupCalls * 3 * state_floats() * B))
+        return rc;
     lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) : (size_t)0);
     if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
         lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
@@ -904,6 +989,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             per_cu = std::min(per_cu, v);
         }
         UMX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        n_cus = cus;
         lstm_capacity = per_cu * cus;
         if (const char *e = getenv("UMX_LSTM_NO_OVERLAP")) // testing: never run two LSTM grids at once
             if (atoi(e))
@@ -1052,6 +1138,7 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
     if (persistent)
     {
         a.tag_base = next_tag_base();
+        a.abort_at = ((last_flags & UMX_FLAG_DEBUG_LSTM_ABORT) && layer == 1) ? T / 2 : 0;
         // census + arrival counter every launch; the granule area only when the tag epoch wraps
         UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (tag_epoch == 0 ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
         void *kargs[] = {&a};
@@ -1063,7 +1150,8 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
         // UMX_ERR_TIMEOUT, not as a hang.
         // always 8*S workgroups: with round-robin dispatch every XCD then receives S of them and the
         // census can enable the intra-XCD protocol; surplus workgroups (skipped targets) exit at once
-        hipError_t e = hipLaunchKernel(fn, dim3(8 * S), dim3(lstm_threads), kargs, 0, st);
+        hipError_t e = lstm_gate_launch(device, st, 8 * S * (lstm_threads > 512 ? 2 : 1), 2 * n_cus,
+                                        [&] { return hipLaunchKernel(fn, dim3(8 * S), dim3(lstm_threads), kargs, 0, st); });
         if (e != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1144,8 +1232,10 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         a.t_begin = 0;
         a.t_end = T;
         a.census = 1;
+        a.abort_at = ((last_flags & UMX_FLAG_DEBUG_LSTM_ABORT) && layer == 1) ? T / 2 : 0;
         UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (clear ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
-        hipError_t e = hipLaunchKernel(fn, dim3(8 * S), dim3(LSTM_THREADS), kargs, lds, st);
+        hipError_t e = lstm_gate_launch(device, st, 8 * S * 2, 2 * n_cus,
+                                        [&] { return hipLaunchKernel(fn, dim3(8 * S), dim3(LSTM_THREADS), kargs, lds, st); });
         if (e != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1156,6 +1246,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     if (!persistent)
     {
         a.census = 0;
+        a.abort_at = 0;
         for (int step = 0; step < T; ++step)
         {
             a.t_begin = step;
@@ -1570,6 +1661,21 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
                     sl.lane[ln].ta[tg].mask_dbg = all + (size_t)ln * T * NOUT;
             }
     last_flags = flags;
+    const size_t call_idx = pending.size();
+    {
+        PendingCall pc;
+        memset(&pc, 0, sizeof pc);
+        pc.nb = nb;
+        pc.flags = flags;
+        for (int ln = 0; ln < nb; ++ln)
+        {
+            pc.audio[ln] = audio_dev[ln];
+            pc.n[ln] = n[ln];
+            for (int s2 = 0; s2 < 4; ++s2)
+                pc.out[4 * ln + s2] = out[4 * ln + s2];
+        }
+        pending.push_back(pc);
+    }
     if (int rc = stage_front(sl, st, nb, audio_dev, n, active, nact))
         return rc;
     // two LSTM grids at once only where both fit (the single-track kernel); otherwise wait for the previous
@@ -1585,6 +1691,9 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
         if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3)
             UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[two_grids ? layer : 2], 0));
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
+        if (call_idx < (size_t)kBackupCalls) // the state this layer starts from (the previous segment's layer has finished)
+            UMX_HIP_CHECK(hipMemcpyAsync(backup + (call_idx * 3 + layer) * state_floats() * B, state, sizeof(float) * state_floats() * B,
+                                         hipMemcpyDeviceToDevice, st));
         if (nact > 0)
             if (int rc = run_lstm_layer(sl, layer, active, nact, flags & UMX_FLAG_LSTM_STEPWISE, lane_mask))
                 return rc;
@@ -1606,11 +1715,47 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
 int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, float *const out_host[4], unsigned flags,
                        void (*progress)(float, void *), void *progress_user)
 {
-    if (!audio_host || !out_host || length < 1 || shift_offset >= UMX_MAX_SHIFT)
+    if (!out_host)
     {
         set_error("track: need audio, outputs, length >= 1 and shift offset < 22050");
         return UMX_ERR_ARG;
     }
+    return tracks(1, &audio_host, &length, &shift_offset, out_host, flags, progress, progress_user);
+}
+
+// shift_inference (umx.cpp:99-150) around split_inference (umx.cpp:152-295) for `nt` tracks at once, one per track
+// lane: the tracks stay in HBM, call s runs segment s of every track that still has one (a finished track's lane sits
+// idle), the weighted overlap-add and the normalisation run per lane on the device, finished regions are downloaded
+// while later segments run.  nt == 1 is umx_hip_split_inference / umx_hip_shift_inference.
+int umx_hip_ctx::tracks(int nt, const float *const *audio_host, const int *length, const int *shift_offset, float *const *out_host,
+                        unsigned flags, void (*progress)(float, void *), void *progress_user)
+{
+    // A persistent-kernel timeout inside a track cannot be repaired segment by segment (the overlap-add has consumed
+    // the stems): everything is run again, once, with the per-step driver the timeout switches the context to.
+    no_recovery = true;
+    int rc = tracks_once(nt, audio_host, length, shift_offset, out_host, flags, progress, progress_user);
+    if (rc == UMX_ERR_TIMEOUT)
+        rc = tracks_once(nt, audio_host, length, shift_offset, out_host, flags, progress, progress_user);
+    no_recovery = false;
+    pending.clear();
+    return rc;
+}
+
+int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *length, const int *shift_offset, float *const *out_host,
+                             unsigned flags, void (*progress)(float, void *), void *progress_user)
+{
+    if (nt < 1 || nt > B || !audio_host || !length || !shift_offset || !out_host)
+    {
+        set_error("tracks: need 1 <= n_tracks <= the context's track count and non-null argument arrays");
+        return UMX_ERR_ARG;
+    }
+    for (int ln = 0; ln < nt; ++ln)
+        if (!audio_host[ln] || length[ln] < 1 || shift_offset[ln] >= UMX_MAX_SHIFT || !out_host[4 * ln] || !out_host[4 * ln + 1] ||
+            !out_host[4 * ln + 2] || !out_host[4 * ln + 3])
+        {
+            set_error("track: need audio, outputs, length >= 1 and shift offset < 22050");
+            return UMX_ERR_ARG;
+        }
     if (ph_next != -1)
     {
         set_error("track: a phased segment is open (umx_hip_segment_end first)");
@@ -1619,71 +1764,82 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     UMX_HIP_CHECK(hipSetDevice(device));
     if (int rc = sync_all())
         return rc;
-    const int lead = shift_offset < 0 ? 0 : shift_offset;
-    // umx.cpp:120-122: length + max_shift - offset -- which the reference overruns for offset > max_shift / 2 (its
-    // block write is [offset, offset + length)); the same size where the reference is defined, large enough elsewhere
-    const long long L2ll = shift_offset < 0 ? (long long)length : (long long)length + std::max(UMX_MAX_SHIFT - shift_offset, shift_offset);
-    if (L2ll > 0x7fffffff / 2)
+    int lead[LSTMB_MAX_TRACKS], L2[LSTMB_MAX_TRACKS], L2max = 0;
+    for (int ln = 0; ln < nt; ++ln)
     {
-        set_error("track: too long");
-        return UMX_ERR_ARG;
-    }
-    const int L2 = (int)L2ll;
-    if ((size_t)L2 > trk_cap) // grow-only track buffers
-    {
-        const size_t cap = (size_t)L2 + (size_t)L2 / 8;
-        for (float **p : {&trk_in, &trk_out[0], &trk_out[1], &trk_out[2], &trk_out[3], &trk_sumw})
-            if (*p)
-            {
-                allocs.erase(std::find(allocs.begin(), allocs.end(), (void *)*p));
-                (void)hipFree(*p);
-                *p = nullptr;
-            }
-        trk_cap = 0;
-        if (int rc = dalloc(&trk_in, 2 * cap, false))
-            return rc;
-        for (int t = 0; t < 4; ++t)
-            if (int rc = dalloc(&trk_out[t], 2 * cap, false))
-                return rc;
-        if (int rc = dalloc(&trk_sumw, cap, false))
-            return rc;
-        trk_cap = cap;
-    }
-    if (!trk_seg[0][0])
-    {
-        for (int s = 0; s < 2; ++s)
+        lead[ln] = shift_offset[ln] < 0 ? 0 : shift_offset[ln];
+        // umx.cpp:120-122: length + max_shift - offset -- which the reference overruns for offset > max_shift / 2 (its
+        // block write is [offset, offset + length)); the same size where the reference is defined, large enough elsewhere
+        const long long l2 = shift_offset[ln] < 0 ? (long long)length[ln]
+                                                  : (long long)length[ln] + std::max(UMX_MAX_SHIFT - shift_offset[ln], shift_offset[ln]);
+        if (l2 > 0x7fffffff / 2)
         {
-            for (int t = 0; t < 4; ++t)
-                if (int rc = dalloc(&trk_seg[s][t], (size_t)2 * N, false))
-                    return rc;
-            UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
+            set_error("track: too long");
+            return UMX_ERR_ARG;
         }
+        L2[ln] = (int)l2;
+        L2max = std::max(L2max, L2[ln]);
     }
+    if (trk.size() < (size_t)nt)
+        trk.resize(nt);
+    for (int ln = 0; ln < nt; ++ln)
+    {
+        TrackBufs &tb_ = trk[ln];
+        if ((size_t)L2[ln] > tb_.cap) // grow-only track buffers
+        {
+            const size_t cap = (size_t)L2[ln] + (size_t)L2[ln] / 8;
+            for (float **p : {&tb_.in, &tb_.out[0], &tb_.out[1], &tb_.out[2], &tb_.out[3], &tb_.sumw})
+                if (*p)
+                {
+                    allocs.erase(std::find(allocs.begin(), allocs.end(), (void *)*p));
+                    (void)hipFree(*p);
+                    *p = nullptr;
+                }
+            tb_.cap = 0;
+            if (int rc = dalloc(&tb_.in, 2 * cap, false))
+                return rc;
+            for (int t = 0; t < 4; ++t)
+                if (int rc = dalloc(&tb_.out[t], 2 * cap, false))
+                    return rc;
+            if (int rc = dalloc(&tb_.sumw, cap, false))
+                return rc;
+            tb_.cap = cap;
+        }
+        if (!tb_.seg[0][0])
+            for (int s = 0; s < 2; ++s)
+                for (int t = 0; t < 4; ++t)
+                    if (int rc = dalloc(&tb_.seg[s][t], (size_t)2 * N, false))
+                        return rc;
+    }
+    if (!trk_acc_ev[0])
+        for (int s = 0; s < 2; ++s)
+            UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
     const bool timing = getenv("UMX_TRACK_TIMING") != nullptr;
     const auto tt0 = std::chrono::steady_clock::now();
     // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
-    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats())); // track lane 0
+    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats() * nt));
     slot[0].used = slot[1].used = false;
-    UMX_HIP_CHECK(hipMemset(trk_in, 0, sizeof(float) * 2 * (size_t)L2));
-    for (int t = 0; t < 4; ++t)
-        UMX_HIP_CHECK(hipMemset(trk_out[t], 0, sizeof(float) * 2 * (size_t)L2));
-    UMX_HIP_CHECK(hipMemset(trk_sumw, 0, sizeof(float) * (size_t)L2));
-    UMX_HIP_CHECK(hipMemcpy(trk_in + 2 * (size_t)lead, audio_host, sizeof(float) * 2 * (size_t)length, hipMemcpyHostToDevice));
+    for (int ln = 0; ln < nt; ++ln)
+    {
+        TrackBufs &tb_ = trk[ln];
+        UMX_HIP_CHECK(hipMemset(tb_.in, 0, sizeof(float) * 2 * (size_t)L2[ln]));
+        for (int t = 0; t < 4; ++t)
+            UMX_HIP_CHECK(hipMemset(tb_.out[t], 0, sizeof(float) * 2 * (size_t)L2[ln]));
+        UMX_HIP_CHECK(hipMemset(tb_.sumw, 0, sizeof(float) * (size_t)L2[ln]));
+        UMX_HIP_CHECK(hipMemcpy(tb_.in + 2 * (size_t)lead[ln], audio_host[ln], sizeof(float) * 2 * (size_t)length[ln], hipMemcpyHostToDevice));
+    }
     UMX_HIP_CHECK(hipDeviceSynchronize());
 
     const auto tt1 = std::chrono::steady_clock::now();
-    Stems4 trk;
-    for (int t = 0; t < 4; ++t)
-        trk.p[t] = reinterpret_cast<float2 *>(trk_out[t]);
     const int stride = (int)((1 - 0.25f) * N); // umx.cpp:181, inference.hpp:15
-    const float total_reps = std::ceil((float)L2 / (float)stride); // umx.cpp:208
+    const float total_reps = std::ceil((float)L2max / (float)stride); // umx.cpp:208 (of the longest track)
     float done = 0.f;
     // A sample is final once the segment that starts at or before it and the one before that have been blended
     // in: region [offset_i, offset_{i+1}) right after segment i.  It is normalised there and then, and the host
     // downloads it while the GPU is already busy with the following segments.
     struct Region
     {
-        int start, count;
+        int lane, start, count;
         hipEvent_t ready;
     };
     std::vector<Region> regions;
@@ -1692,11 +1848,22 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
             (void)hipEventDestroy(r.ready);
     };
     int last_slot = -1, iseg = 0;
-    for (long long off = 0; off < L2; off += stride, ++iseg)
+    for (long long off = 0; off < L2max; off += stride, ++iseg)
     {
-        const int offset = (int)off, n = std::min(N, L2 - offset); // umx.cpp:214-217
+        const int offset = (int)off;
         const int si = (int)(nseg & 1);
-        const int rc = infer_device(trk_in + 2 * (size_t)offset, n, trk_seg[si], flags);
+        const float *ain[LSTMB_MAX_TRACKS] = {};
+        int nn[LSTMB_MAX_TRACKS] = {};
+        float *outs[4 * LSTMB_MAX_TRACKS] = {};
+        for (int ln = 0; ln < nt; ++ln)
+            if (offset < L2[ln]) // this track still has a segment here (umx.cpp:214-217)
+            {
+                ain[ln] = trk[ln].in + 2 * (size_t)offset;
+                nn[ln] = std::min(N, L2[ln] - offset);
+                for (int t = 0; t < 4; ++t)
+                    outs[4 * ln + t] = trk[ln].seg[si][t];
+            }
+        const int rc = infer_batch(nt, ain, nn, outs, flags);
         if (rc)
         {
             cleanup();
@@ -1705,23 +1872,32 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
         hipStream_t st = slot[si].stream;
         if (last_slot >= 0) // accumulate in segment order (two segments overlap by a quarter)
             (void)hipStreamWaitEvent(st, trk_acc_ev[last_slot], 0);
-        Stems4 seg;
-        for (int t = 0; t < 4; ++t)
-            seg.p[t] = reinterpret_cast<float2 *>(trk_seg[si][t]);
-        hipLaunchKernelGGL(track_accumulate_kernel, dim3((n + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, seg, offset, n, N);
+        for (int ln = 0; ln < nt; ++ln)
+        {
+            if (!ain[ln])
+                continue;
+            Stems4 tk, seg;
+            for (int t = 0; t < 4; ++t)
+            {
+                tk.p[t] = reinterpret_cast<float2 *>(trk[ln].out[t]);
+                seg.p[t] = reinterpret_cast<float2 *>(trk[ln].seg[si][t]);
+            }
+            hipLaunchKernelGGL(track_accumulate_kernel, dim3((nn[ln] + 255) / 256, 4), dim3(256), 0, st, tk, trk[ln].sumw, seg, offset, nn[ln], N);
+            Region rg;
+            rg.lane = ln;
+            rg.start = offset;
+            rg.count = (int)std::min<long long>(off + stride, L2[ln]) - offset;
+            hipLaunchKernelGGL(track_normalise_kernel, dim3((rg.count + 255) / 256, 4), dim3(256), 0, st, tk, trk[ln].sumw, rg.start, rg.count);
+            if (hipEventCreateWithFlags(&rg.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(rg.ready, st) != hipSuccess)
+            {
+                cleanup();
+                set_error("track: event creation failed");
+                return UMX_ERR_HIP;
+            }
+            regions.push_back(rg);
+        }
         (void)hipEventRecord(trk_acc_ev[si], st);
         last_slot = si;
-        Region rg;
-        rg.start = offset;
-        rg.count = (int)std::min<long long>(off + stride, L2) - offset;
-        hipLaunchKernelGGL(track_normalise_kernel, dim3((rg.count + 255) / 256, 4), dim3(256), 0, st, trk, trk_sumw, rg.start, rg.count);
-        if (hipEventCreateWithFlags(&rg.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(rg.ready, st) != hipSuccess)
-        {
-            cleanup();
-            set_error("track: event creation failed");
-            return UMX_ERR_HIP;
-        }
-        regions.push_back(rg);
         done += 1.0f / total_reps; // umx.cpp:229 (queued, not finished: the device runs behind the host here)
         if (progress)
             progress(done, progress_user);
@@ -1730,14 +1906,16 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     hipError_t cerr = hipSuccess;
     for (const Region &rg : regions) // umx.cpp:136-147: drop the shift
     {
-        const long long lo = std::max<long long>(rg.start, lead), hi = std::min<long long>((long long)rg.start + rg.count, (long long)lead + length);
+        const int ln = rg.lane;
+        const long long lo = std::max<long long>(rg.start, lead[ln]),
+                        hi = std::min<long long>((long long)rg.start + rg.count, (long long)lead[ln] + length[ln]);
         if (hi <= lo)
             continue;
         if (cerr == hipSuccess)
             cerr = hipEventSynchronize(rg.ready);
         for (int t = 0; t < 4 && cerr == hipSuccess; ++t)
-            cerr = hipMemcpy(out_host[t] + 2 * (size_t)(lo - lead), trk_out[t] + 2 * (size_t)lo, sizeof(float) * 2 * (size_t)(hi - lo),
-                             hipMemcpyDeviceToHost);
+            cerr = hipMemcpy(out_host[4 * ln + t] + 2 * (size_t)(lo - lead[ln]), trk[ln].out[t] + 2 * (size_t)lo,
+                             sizeof(float) * 2 * (size_t)(hi - lo), hipMemcpyDeviceToHost);
     }
     cleanup();
     if (cerr != hipSuccess)
@@ -1752,8 +1930,8 @@ int umx_hip_ctx::track(const float *audio_host, int length, int shift_offset, fl
     {
         const auto tt3 = std::chrono::steady_clock::now();
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[umx track] %d samples: clear+upload %.1f ms, queuing %d segments %.1f ms, segments + overlapped download %.1f ms\n",
-                length, ms(tt0, tt1), iseg, ms(tt1, tt2), ms(tt2, tt3));
+        fprintf(stderr, "[umx track] %d track(s), longest %d samples: clear+upload %.1f ms, queuing %d segment calls %.1f ms, segments + overlapped "
+                        "download %.1f ms\n", nt, L2max, ms(tt0, tt1), iseg, ms(tt1, tt2), ms(tt2, tt3));
     }
     return UMX_OK;
 }
@@ -1918,6 +2096,35 @@ __global__ __launch_bounds__(256) void lds_guard_kernel(unsigned *errs, int roun
         __syncthreads();
         __builtin_amdgcn_s_sleep(32);
     }
+}
+
+// After a persistent-kernel timeout (everything has drained): put the stream state back to what it was before the
+// first call queued since the last sync, layer by layer, and run those calls again with the per-step driver.
+int umx_hip_ctx::recover()
+{
+    std::vector<PendingCall> calls;
+    calls.swap(pending);
+    const size_t per = state_floats();
+    for (int l = 0; l < 3; ++l) // layer l of every (lane, target): 4 * Hl floats every 12 * Hl
+        UMX_HIP_CHECK(hipMemcpy2D(state + (size_t)l * 4 * Hl, sizeof(float) * 12 * Hl, backup + (size_t)l * per * B + (size_t)l * 4 * Hl,
+                                  sizeof(float) * 12 * Hl, sizeof(float) * 4 * Hl, (size_t)B * 4, hipMemcpyDeviceToDevice));
+    slot[0].used = slot[1].used = false;
+    recovering = true;
+    int rc = UMX_OK;
+    for (const PendingCall &pc : calls)
+    {
+        if ((rc = infer_batch(pc.nb, pc.audio, pc.n, pc.out, (pc.flags | UMX_FLAG_LSTM_STEPWISE) & ~UMX_FLAG_DEBUG_LSTM_ABORT)) != UMX_OK)
+            break;
+        for (int k = 0; k < 4 * pc.nb; ++k) // the host-pointer forms had copied the failed run's stems out
+            if (pc.host_out[k] && pc.audio[k / 4])
+                UMX_HIP_CHECK(hipMemcpyAsync(pc.host_out[k], pc.out[k], sizeof(float) * 2 * (size_t)pc.n[k / 4], hipMemcpyDeviceToHost,
+                                             slot[cur].stream));
+    }
+    recovering = false;
+    if (rc == UMX_OK)
+        rc = sync_all();
+    pending.clear();
+    return rc;
 }
 
 // ---------------------------------------------------------------- C-ABI
@@ -2102,6 +2309,11 @@ int umx_hip_split_inference(umx_hip_ctx *ctx, const float *audio_host, int lengt
 {
     return ctx ? ctx->track(audio_host, length, -1, out_host, flags, progress, progress_user) : UMX_ERR_ARG;
 }
+int umx_hip_separate_tracks(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *length, const int *shift_offset,
+                            float *const *out_host, unsigned flags, void (*progress)(float, void *), void *progress_user)
+{
+    return ctx ? ctx->tracks(n_tracks, audio_host, length, shift_offset, out_host, flags, progress, progress_user) : UMX_ERR_ARG;
+}
 int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int length, int offset, float *const out_host[4],
                             unsigned flags, void (*progress)(float, void *), void *progress_user)
 {
@@ -2263,20 +2475,32 @@ int umx_hip_sync(umx_hip_ctx *ctx)
         }
         if (st != 0)
         {
-            // the aborted launch left a mix of updated and stale chains behind: the stream state of every track
-            // lane is reset, and the caller is told so (continuing a track after this needs umx_hip_*stream_set)
+            const std::string what = st == 0x80000000u
+                                         ? std::string("persistent LSTM kernel: grid barrier timed out (grid not co-resident)")
+                                         : "persistent LSTM kernel timed out waiting for a hidden-state granule (code " + std::to_string(st) + ")";
+            for (int sj = 0; sj < ctx->nslots; ++sj)
+                (void)hipMemset(ctx->slot[sj].status, 0, sizeof(unsigned));
+            ctx->persistent_ok = false; // later launches use the per-step driver
+            const size_t ncalls = ctx->pending.size();
+            if (!ctx->no_recovery && ncalls >= 1 && ncalls <= (size_t)umx_hip_ctx::kBackupCalls)
+            {
+                const int rc = ctx->recover();
+                if (rc == UMX_OK)
+                {
+                    ctx->set_error("recovered: " + what + "; " + std::to_string(ncalls) + " queued segment call(s) were run again with the "
+                                   "per-step LSTM driver (bit-identical), which later calls of this context use as well");
+                    return UMX_OK;
+                }
+            }
+            // no way back: the aborted launch left a mix of updated and stale chains behind
             (void)hipMemset(ctx->state, 0, sizeof(float) * ctx->state_floats() * ctx->B);
             ctx->slot[0].used = ctx->slot[1].used = false;
-            ctx->set_error((st == 0x80000000u
-                                ? std::string("persistent LSTM kernel: grid barrier timed out (grid not co-resident)")
-                                : "persistent LSTM kernel timed out waiting for a hidden-state granule (code " +
-                                      std::to_string(st) + ")") +
-                           "; the streaming LSTM state was reset to zero, later segments run the per-step driver");
-            (void)hipMemset(dev_status, 0, sizeof(unsigned));
-            ctx->persistent_ok = false;
+            ctx->pending.clear();
+            ctx->set_error(what + "; the streaming LSTM state was reset to zero, later segments run the per-step driver");
             return UMX_ERR_TIMEOUT;
         }
     }
+    ctx->pending.clear();
     return UMX_OK;
 }
 
@@ -2316,6 +2540,8 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
     }
     if (int rc = ctx->infer_batch(n_tracks, ain, n, ctx->stage_out[si], flags))
         return rc;
+    for (int k = 0; k < 4 * n_tracks; ++k)
+        ctx->pending.back().host_out[k] = out_host[k];
     for (int ln = 0; ln < n_tracks; ++ln)
         if (ain[ln])
             for (int s = 0; s < 4; ++s)

@@ -82,6 +82,7 @@ struct LstmBArgs
     int nbp;            // lanes the LDS arrays are sized for: power of two >= highest active lane + 1
     int bulk;           // W_ih-row ring: rows per bulk fetch (ring = 2 * bulk rows)
     int t_begin, t_end; // steps of this launch
+    int abort_at;       // testing: every workgroup gives up at this step as if a poll had timed out (0 = never)
     int census;         // 1: take the census (t_end - t_begin > 1: needs the grid co-resident); 0: static roles
 };
 
@@ -251,6 +252,11 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (prof)
             c0 = clock64();
+        if (a.abort_at && step == a.abort_at && tid == 0)
+        {
+            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *abort_flag = 1;
+        }
         if (dot_wave)
         {
             if (step > t_begin)

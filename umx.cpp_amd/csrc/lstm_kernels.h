@@ -76,6 +76,7 @@ struct LstmArgs
     int Hl, S, T, ldp, ldo, col0, layer, nchains;
     int tmap[4];      // chain>>1 -> target (targets can be skipped: BASELINE config 1)
     int force_safe;   // 1 = never use the intra-XCD protocol (testing)
+    int abort_at;      // testing (UMX_FLAG_DEBUG_LSTM_ABORT): every workgroup gives up at this step as if a poll had timed out
     unsigned tag_base; // granule tag of step s = tag_base + s + 1: unique per launch, so a granule line left in
                        // some L2 by an earlier launch can never pass for this launch's data
 };
@@ -574,6 +575,11 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (prof)
             c0 = clock64();
+        if (a.abort_at && step == a.abort_at && tid == 0)
+        {
+            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *abort_flag = 1;
+        }
         if (dot_wave)
         {
             if (step > 0)
