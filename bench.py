@@ -286,7 +286,7 @@ def main():
         seg_sec = N / 44100.0
         value = world * B * args.steps * seg_sec / dt
         gemm, rec, byt = algorithmic_work(T, H)
-        flavour = args.gemm or os.environ.get("UMX_GEMM", "planes")
+        flavour = args.gemm or os.environ.get("UMX_GEMM") or ("planes" if batched else "bf16x3")
         traffic_src = args.traffic_csv or next(iter(sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_fetch_write_per_kernel.csv")),
                                                            reverse=True)), None)
         traffic = read_traffic(traffic_src) if traffic_src else {}
@@ -299,10 +299,11 @@ def main():
 
         # ---- one entry per kernel family: launches per step, live duration per launch, work per launch, roof
         def gemm_entry(stage_keys, work_key, products, name, tneedles):
-            launches = len(stage_keys) * B
+            # the plane GEMMs cover all track lanes in one launch (the stage also holds the small split_planes launch)
+            launches = len(stage_keys) * (1 if flavour == "planes" else B)
             ms = sum(stage_ms.get(kk, 0.0) for kk in stage_keys) / launches
             ms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in stage_keys) / launches
-            alg = gemm[work_key]
+            alg = gemm[work_key] * (B if flavour == "planes" else 1)
             issued = alg * products if flavour != "f32" else alg
             peak = BF16_MFMA_PEAK_TF if flavour != "f32" else F32_MFMA_PEAK_TF
             ach = issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -317,10 +318,11 @@ def main():
         exact = planes and not args.expanded_weights and not args.u8_dequant  # integer weights as exact bf16 terms
         p8 = 3 if exact else 6
         p16 = 5 if (exact and flavour == "planes") else 6
-        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gname}<G_FC1>", (gname, "ILi0E")),
-                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gname}<G_IH>", (gname, "ILi1E")),
-                   gemm_entry(["fc2"], "fc2", p16, f"{gname}<G_FC2>", (gname, "ILi2E")),
-                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{gname}<G_FC3>", (gname, "ILi3E"))]
+        # (the PMC summary holds demangled names: "void umx::gemm_planes_kernel<1, 1, 4, 4>(umx::GemmPArgs)" = <MODE, planes of B, WM, WN>)
+        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gname}<G_FC1>", (gname + "<0,",)),
+                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gname}<G_IH>", (gname + "<1,",)),
+                   gemm_entry(["fc2"], "fc2", p16, f"{gname}<G_FC2>", (gname + "<2,",)),
+                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{gname}<G_FC3>", (gname + "<3,",))]
         lstm_keys = [f"lstm_rec{l}" for l in range(3)]
         lms = sum(stage_ms.get(kk, 0.0) for kk in lstm_keys) / 3
         lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3

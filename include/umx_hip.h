@@ -95,12 +95,16 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
  * product, the size of one fp32 rounding of the sum).  UMX_CREATE_U8_DEQUANT (environment UMX_U8=dequant) keeps the
  * per-weight form (dequantise, split in three, six products): bit-identical to UMX_CREATE_DEQUANTISE_AT_LOAD. */
 #define UMX_CREATE_U8_DEQUANT 0x20u
-/* The bf16 GEMM flavour exists in two forms.  Default (csrc/gemm_planes.h): every activation matrix is split once into
- * three bf16 planes (+ row sums) by a small kernel, every weight matrix is re-encoded once at load time as exact bf16
- * integer planes (u8: 1, u16: 2; fp32: 3 split terms), and the GEMM itself only moves tiles global -> LDS by DMA and
- * issues matrix-core instructions.  UMX_CREATE_GEMM_STAGED (environment UMX_GEMM=bf16x3) selects round 1's kernel
- * (csrc/gemm_bf16x3.h), which keeps u8 / u16 weights as stored and splits both operands while staging every tile. */
+/* The bf16 GEMM flavour exists in two forms.  csrc/gemm_planes.h (default of track-batched contexts): every activation
+ * matrix is split once into three bf16 planes (+ row sums) by a small kernel, every weight matrix is re-encoded once
+ * at load time as exact bf16 integer planes (u8: 1, u16: 2; fp32: 3 split terms), and the GEMM itself only moves
+ * 256 x 256 tiles global -> LDS by DMA, over all track lanes at once, and issues matrix-core instructions.
+ * csrc/gemm_bf16x3.h (default of single-track contexts): keeps u8 / u16 weights as stored and splits both operands while
+ * staging every 128 x 128 tile; small enough in registers and LDS to share the CUs with the two co-resident single-track
+ * LSTM grids of the latency pipeline.  UMX_CREATE_GEMM_STAGED / UMX_CREATE_GEMM_PLANES (environment UMX_GEMM=bf16x3 /
+ * planes) force one or the other. */
 #define UMX_CREATE_GEMM_STAGED 0x40u
+#define UMX_CREATE_GEMM_PLANES 0x80u
 int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 /* Track batching.  The reference is one track per process (umx.cpp:26-97) and its LSTM is one

@@ -315,11 +315,12 @@ def test_device_resident_track_equals_host_split_and_shift(pkg, small):
 
 
 def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_path):
-    """The dense stack runs on the bf16 matrix cores by default (fp32 operands split into three bf16 terms, six
-    products, fp32 accumulation: csrc/gemm_bf16x3.h); gemm="f32" keeps the fp32-MFMA kernels.  Both must sit within
-    the same distance of the oracle, agree with each other to fp32 rounding, and -- for either flavour -- queuing
-    segments back to back must give the bits of one segment at a time (co-residency of bf16 MFMA waves with other
-    kernels' waves is what this guards)."""
+    """The dense stack runs on the bf16 matrix cores (fp32 activations split into three bf16 terms, fp32 accumulation):
+    gemm="bf16x3" splits while it stages every tile (csrc/gemm_bf16x3.h, the single-track default), gemm="planes" consumes
+    pre-split operands by LDS-DMA (csrc/gemm_planes.h, the track-batched default); gemm="f32" keeps the fp32-MFMA
+    kernels.  All must sit within the same distance of the oracle, agree with each other to fp32 rounding, and -- for
+    every flavour -- queuing segments back to back must give the bits of one segment at a time (co-residency of bf16
+    MFMA waves with other kernels' waves is what this guards)."""
     import torch
     torch.zeros(1).cuda()
     path, om, targets = model_small
@@ -328,7 +329,7 @@ def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_pat
     state = po.stream_state(128)
     ref = [po.umx_inference(om, w, n_buf=N, state=state)[0] for w in waves]
     outs = {}
-    for gemm in ("bf16x3", "f32"):
+    for gemm in ("bf16x3", "planes", "f32"):
         eng = pkg.Engine(targets, 128, N, gemm=gemm)
         outs[gemm] = [eng.infer_segment(w) for w in waves]
         eng.close()
@@ -338,13 +339,14 @@ def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_pat
     for i in range(2):
         for t in range(4):
             assert np.abs(outs["bf16x3"][i][t] - outs["f32"][i][t]).max() < 1e-5
+            assert np.abs(outs["planes"][i][t] - outs["f32"][i][t]).max() < 1e-5
     # UMX-L width, pipelined == serial, both flavours
     H, N, NSEG = 1024, 40 * 1024, 6
     p = str(tmp_path / "m.bin")
     pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=33), H, compress=False)
     waves = [pkg.ggml.synth_audio(N, 610 + i) for i in range(NSEG)]
     ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda() for w in waves]
-    for gemm in ("bf16x3", "f32"):
+    for gemm in ("bf16x3", "planes", "f32"):
         eng = pkg.Engine.from_file(p, N, gemm=gemm)
         eng.stream_reset()
         serial = [eng.infer_segment(w) for w in waves]

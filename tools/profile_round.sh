@@ -1,15 +1,15 @@
 #!/bin/bash
 # tools/profile_round.sh <tag>: the rocprofv3 evidence of one build, written under gpurun_out/prof_<tag>/
 # (kernel trace of the pipelined bench; FETCH_SIZE and WRITE_SIZE in separate counter passes, serial segments)
-tag=${1:-r01_v3}
+tag=${1:-r02_v1}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python $R/bench.py --steps 12 --warmup 3 > $out/bench.json 2> $out/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.err
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> $out/pmc_fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --serial > /dev/null 2> $out/pmc_write.err
+python $R/bench.py > $out/bench.json 2> $out/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-single-track > $out/bench_under_rocprof.json 2> $out/trace.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-single-track --serial > /dev/null 2> $out/pmc_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-single-track --serial > /dev/null 2> $out/pmc_write.err
 cd $R
 python - <<PY
 import csv, glob, collections, os

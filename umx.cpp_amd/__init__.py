@@ -138,6 +138,7 @@ CREATE_DEQUANTISE_AT_LOAD = 0x8
 CREATE_LSTM_BATCHED = 0x10
 CREATE_U8_DEQUANT = 0x20
 CREATE_GEMM_STAGED = 0x40
+CREATE_GEMM_PLANES = 0x80
 MAX_TRACKS = 16
 
 HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "umx_hip_n_tracks", "umx_hip_lstm_is_batched",
@@ -192,8 +193,9 @@ class Engine:
                  quantised_resident=True, gemm=None, tracks=1, lstm_batched=False, u8_dequant=False):
         """quantised: hand the file's u8/u16 bytes (+ scale/offset) to the engine instead of fp32 arrays;
         quantised_resident: keep them that way in HBM (the default; BASELINE config 5) or expand them at load;
-        gemm: "planes" (default: bf16 matrix cores, operands pre-split into bf16 planes, LDS-DMA staging), "bf16x3" (the
-        same arithmetic with both operands split while every tile is staged) or "f32" (fp32 MFMA);
+        gemm: "planes" (bf16 matrix cores, operands pre-split into bf16 planes, LDS-DMA staging: the default with tracks > 1
+        or lstm_batched), "bf16x3" (the same arithmetic with both operands split while every tile is staged: the default of
+        the single-track engine) or "f32" (fp32 MFMA);
         tracks: independent track lanes (1..16) run together per call (infer_batch*);
         lstm_batched: use the batched (matrix-core) LSTM kernel also on a 1-track context."""
         self.lib = hip_lib()
@@ -201,8 +203,8 @@ class Engine:
         h = C.c_void_p()
         rc = self.lib.umx_hip_create_tracks(C.byref(h), device, hidden, segment_samples, views, len(views),
                                             (0 if quantised_resident else CREATE_DEQUANTISE_AT_LOAD) |
-                                            (CREATE_GEMM_F32 if (gemm or os.environ.get("UMX_GEMM", "planes")) == "f32" else 0) |
-                                            (CREATE_GEMM_STAGED if (gemm or os.environ.get("UMX_GEMM", "planes")) == "bf16x3" else 0) |
+                                            {"f32": CREATE_GEMM_F32, "bf16x3": CREATE_GEMM_STAGED, "planes": CREATE_GEMM_PLANES}.get(
+                                                gemm or os.environ.get("UMX_GEMM", ""), 0) |
                                             (CREATE_LSTM_BATCHED if lstm_batched else 0) |
                                             (CREATE_U8_DEQUANT if (u8_dequant or os.environ.get("UMX_U8") == "dequant") else 0), tracks)
         if rc != UMX_OK:

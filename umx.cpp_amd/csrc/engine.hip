@@ -494,7 +494,10 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     };
 
     gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // the bf16 matrix cores are the default
-    gemm_planes = gemm_bf16x3 && !(create_flags & UMX_CREATE_GEMM_STAGED); // gemm_planes.h unless gemm_bf16x3.h is asked for
+    // gemm_planes.h for track-batched contexts (large tiles over all lanes); gemm_bf16x3.h for the single-track,
+    // latency-optimised context, whose pipeline overlaps small GEMM blocks with two co-resident LSTM grids (the register
+    // and LDS budget of DESIGN 4.2 was tuned for exactly that kernel).  Either can be forced.
+    gemm_planes = gemm_bf16x3 && ((create_flags & UMX_CREATE_GEMM_PLANES) || (lstm_batched && !(create_flags & UMX_CREATE_GEMM_STAGED)));
     const bool bx = gemm_bf16x3;
     // A GEMM weight as exact bf16 planes (PMat): (rows x cols) of `tv` (u8 / u16 as stored) or of `f32`, source row
     // rowmap[r] -> destination row dst_row0 + r of a [nbp][total_rows][cols_pad] matrix built in `host`
@@ -2144,6 +2147,8 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
             cf |= UMX_CREATE_GEMM_F32;
         if (std::string(e) == "bf16x3")
             cf |= UMX_CREATE_GEMM_STAGED;
+        if (std::string(e) == "planes")
+            cf |= UMX_CREATE_GEMM_PLANES;
     }
     if (const char *e = getenv("UMX_LSTM"))
         if (std::string(e) == "batched")
