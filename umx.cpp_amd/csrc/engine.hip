@@ -46,12 +46,13 @@ struct QMat
     float s[2] = {1.f, 1.f}, o[2] = {0.f, 0.f};
 };
 
-// A GEMM weight as exact bf16 planes [nbp][N][K] (gemm_planes.h): u8 -> 1 plane of q - 128, u16 -> 2 planes
-// 256 (qh - 128), ql - 128, fp32 -> 3 split terms; (scale, offset + c scale) per file tensor (W_ih: two).
+// A GEMM weight as fp16 planes [nbp][N][K] (gemm_planes.h): u8 -> 1 exact plane of q - 128, u16 -> 2 exact planes
+// 256 (qh - 128), ql - 128, fp32 -> 2 split terms of w / s with s a power of two; (scale, offset + c scale) per file
+// tensor (W_ih: two).
 struct PMat
 {
     unsigned short *p = nullptr;
-    int nbp = 3;
+    int nbp = 2;
     float s[2] = {1.f, 1.f}, o2[2] = {0.f, 0.f};
 };
 
@@ -70,9 +71,11 @@ struct TargetAct // activations of one target in one pipeline slot
 {
     float *cat = nullptr, *la = nullptr, *lb = nullptr, *P = nullptr, *a2 = nullptr, *mag = nullptr,
           *mask_dbg = nullptr;
-    // gemm_planes.h: every GEMM's A operand split once into three bf16 planes, and its row sums
+    // gemm_planes.h: every GEMM's A operand split once into two fp16 planes of the scaled row, its row sums and (for the
+    // unbounded tensors) its per-row inverse scales
     unsigned short *xs_p = nullptr, *cat_p = nullptr, *la_p = nullptr, *lb_p = nullptr, *a2_p = nullptr;
     float *rs_xs = nullptr, *rs_catL = nullptr, *rs_catR = nullptr, *rs_la = nullptr, *rs_lb = nullptr, *rs_a2 = nullptr;
+    float *rsc_xs = nullptr, *rsc_a2 = nullptr;
 };
 
 enum
@@ -499,31 +502,53 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     // and LDS budget of DESIGN 4.2 was tuned for exactly that kernel).  Either can be forced.
     gemm_planes = gemm_bf16x3 && ((create_flags & UMX_CREATE_GEMM_PLANES) || (lstm_batched && !(create_flags & UMX_CREATE_GEMM_STAGED)));
     const bool bx = gemm_bf16x3;
-    // A GEMM weight as exact bf16 planes (PMat): (rows x cols) of `tv` (u8 / u16 as stored) or of `f32`, source row
+    // A GEMM weight as fp16 planes (PMat): (rows x cols) of `tv` (u8 / u16 as stored: exact integers) or of `f32` (two
+    // split terms of w * 2^e, 2^e bringing the tensor's largest |w| into [2^14, 2^15); returns 2^-e), source row
     // rowmap[r] -> destination row dst_row0 + r of a [nbp][total_rows][cols_pad] matrix built in `host`
     auto fill_planes = [&](std::vector<unsigned short> &host, int nbp, size_t total_rows, int cols_pad, const umx_tensor_view *tv,
-                           const float *f32, int rows, int cols, const std::vector<int> *rowmap, size_t dst_row0) {
+                           const float *f32, int rows, int cols, const std::vector<int> *rowmap, size_t dst_row0) -> float {
         const size_t plane = total_rows * (size_t)cols_pad;
         if (host.empty())
             host.assign((size_t)nbp * plane, 0);
+        float scale = 1.f, unscale = 1.f;
+        if (f32)
+        {
+            float mx = 0.f;
+            for (size_t i = 0; i < (size_t)rows * cols; ++i)
+                if (std::isfinite(f32[i]))
+                    mx = std::max(mx, std::fabs(f32[i]));
+            if (mx > 0.f)
+            {
+                int x;
+                (void)std::frexp(mx, &x);
+                const int e = std::min(std::max(GP_SPLIT_FIXED_EXP + 1 - x, -100), 100);
+                scale = std::ldexp(1.0f, e);
+                unscale = std::ldexp(1.0f, -e);
+            }
+        }
         for (int r = 0; r < rows; ++r)
         {
             const int sr = rowmap ? (*rowmap)[r] : r;
             unsigned short *d = &host[(dst_row0 + r) * cols_pad];
             for (int k = 0; k < cols; ++k)
             {
-                if (nbp == 1)
-                    d[k] = bf16_rne_bits((float)static_cast<const uint8_t *>(tv->data)[(size_t)sr * cols + k] - 128.0f);
-                else if (nbp == 2)
+                if (f32)
+                {
+                    const float w = f32[(size_t)sr * cols + k] * scale;
+                    d[k] = f16_rne_bits(w);
+                    d[plane + k] = f16_rne_bits(w - f16_bits_to_float(d[k]));
+                }
+                else if (nbp == 1)
+                    d[k] = f16_rne_bits((float)static_cast<const uint8_t *>(tv->data)[(size_t)sr * cols + k] - 128.0f);
+                else
                 {
                     const unsigned q = static_cast<const uint16_t *>(tv->data)[(size_t)sr * cols + k];
-                    d[k] = bf16_rne_bits(256.0f * ((float)(q >> 8) - 128.0f));
-                    d[plane + k] = bf16_rne_bits((float)(q & 255u) - 128.0f);
+                    d[k] = f16_rne_bits(256.0f * ((float)(q >> 8) - 128.0f));
+                    d[plane + k] = f16_rne_bits((float)(q & 255u) - 128.0f);
                 }
-                else
-                    split3_host(f32[(size_t)sr * cols + k], d[k], d[plane + k], d[2 * plane + k]);
             }
         }
+        return unscale;
     };
     auto upload_pmat = [&](PMat &pm, std::vector<unsigned short> &host, int nbp) -> int {
         pm.nbp = nbp;
@@ -614,8 +639,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             {
                 if (!get(tg, "fc1.weight", (size_t)H * NIN, v))
                     return UMX_ERR_MODEL;
-                fill_planes(host, 3, H, KX, nullptr, v.data(), H, NIN, nullptr, 0);
-                if (int rc = upload_pmat(b.fc1_p, host, 3))
+                b.fc1_p.s[0] = fill_planes(host, 2, H, KX, nullptr, v.data(), H, NIN, nullptr, 0);
+                if (int rc = upload_pmat(b.fc1_p, host, 2))
                     return rc;
             }
         }
@@ -671,8 +696,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             {
                 if (!get(tg, "fc2.weight", (size_t)H * 2 * H, v))
                     return UMX_ERR_MODEL;
-                fill_planes(host, 3, H, 2 * H, nullptr, v.data(), H, 2 * H, nullptr, 0);
-                if (int rc = upload_pmat(b.fc2_p, host, 3))
+                b.fc2_p.s[0] = fill_planes(host, 2, H, 2 * H, nullptr, v.data(), H, 2 * H, nullptr, 0);
+                if (int rc = upload_pmat(b.fc2_p, host, 2))
                     return rc;
             }
         }
@@ -707,8 +732,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             {
                 if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
                     return UMX_ERR_MODEL;
-                fill_planes(host, 3, NOUT_PAD, H, nullptr, v.data(), NOUT, H, nullptr, 0);
-                if (int rc = upload_pmat(b.fc3_p, host, 3))
+                b.fc3_p.s[0] = fill_planes(host, 2, NOUT_PAD, H, nullptr, v.data(), NOUT, H, nullptr, 0);
+                if (int rc = upload_pmat(b.fc3_p, host, 2))
                     return rc;
             }
         }
@@ -787,7 +812,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                         b.ih_p[l].o2[dir] = ihv[dir]->offset + 128.0f * ihv[dir]->scale;
                     }
                     else
-                        fill_planes(ih_planes, 3, (size_t)2 * G, H, nullptr, wih.data(), G, H, &rowmap, (size_t)dir * G);
+                        b.ih_p[l].s[dir] = fill_planes(ih_planes, 2, (size_t)2 * G, H, nullptr, wih.data(), G, H, &rowmap, (size_t)dir * G);
                 }
                 else if (ih_q)
                 {
@@ -800,7 +825,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             }
             if (gemm_planes)
             {
-                if (int rc = upload_pmat(b.ih_p[l], ih_planes, ih_exact ? 1 : 3))
+                if (int rc = upload_pmat(b.ih_p[l], ih_planes, ih_exact ? 1 : 2))
                     return rc;
             }
             else if (!ih_q)
@@ -908,17 +933,17 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = dalloc(&mag_all, (size_t)B * 2 * T * NBINS))
                 return rc;
             unsigned short *xs_p = nullptr, *cat_p = nullptr, *la_p = nullptr, *lb_p = nullptr, *a2_p = nullptr;
-            float *rs[6] = {};
-            if (gemm_planes) // planes [3][B * Tp][K]: plane-major over ALL lanes, so that M runs across the lanes
+            float *rs[8] = {};
+            if (gemm_planes) // planes [2][B * Tp][K]: plane-major over ALL lanes, so that M runs across the lanes
             {
-                if (int rc = dalloc(&xs_p, (size_t)3 * B * Tp * KX))
+                if (int rc = dalloc(&xs_p, (size_t)2 * B * Tp * KX))
                     return rc;
-                if (int rc = dalloc(&cat_p, (size_t)3 * B * Tp * 2 * H))
+                if (int rc = dalloc(&cat_p, (size_t)2 * B * Tp * 2 * H))
                     return rc;
                 for (unsigned short **q : {&la_p, &lb_p, &a2_p})
-                    if (int rc = dalloc(q, (size_t)3 * B * Tp * H))
+                    if (int rc = dalloc(q, (size_t)2 * B * Tp * H))
                         return rc;
-                for (int k = 0; k < 6; ++k)
+                for (int k = 0; k < 8; ++k)
                     if (int rc = dalloc(&rs[k], (size_t)B * Tp))
                         return rc;
             }
@@ -944,6 +969,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                     b.rs_la = rs[3] + (size_t)ln * Tp;
                     b.rs_lb = rs[4] + (size_t)ln * Tp;
                     b.rs_a2 = rs[5] + (size_t)ln * Tp;
+                    b.rsc_xs = rs[6] + (size_t)ln * Tp;
+                    b.rsc_a2 = rs[7] + (size_t)ln * Tp;
                 }
             }
         }
@@ -1046,7 +1073,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
 #define UMX_GP_ATTR(MODE)                                                                                              \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 2))); \
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 3, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 3))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
         UMX_GP_ATTR(G_FC1)
@@ -1386,7 +1412,7 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
         switch (which)
         {
         case SP_XS: // x * input_scale + input_mean (inference.cpp:78-83), per target
-            a.src[i] = ln.x; a.dst[i] = c.xs_p; a.rowsum[i] = c.rs_xs; a.scale[i] = b.in_scale; a.mean[i] = b.in_mean;
+            a.src[i] = ln.x; a.dst[i] = c.xs_p; a.rowsum[i] = c.rs_xs; a.rowunscale[i] = c.rsc_xs; a.scale[i] = b.in_scale; a.mean[i] = b.in_mean;
             a.cols = KX; a.ld_src = KX; a.ld_dst = KX; a.col0_dst = 0; a.plane = rows_all * KX;
             break;
         case SP_CATL: // fc1 output = left half of the skip concat
@@ -1406,7 +1432,7 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
             a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
             break;
         default:
-            a.src[i] = c.a2; a.dst[i] = c.a2_p; a.rowsum[i] = c.rs_a2;
+            a.src[i] = c.a2; a.dst[i] = c.a2_p; a.rowsum[i] = c.rs_a2; a.rowunscale[i] = c.rsc_a2;
             a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
             break;
         }
@@ -1423,8 +1449,9 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     g.Tp_lane = Tp;
     g.mag_lane = (size_t)2 * T * NBINS;
     g.dbg_lane = (size_t)T * NOUT;
+    g.a_unscale = 1.0f / (float)(1 << GP_SPLIT_FIXED_EXP); // tanh / LSTM outputs: constant scale (split_planes_kernel)
     const size_t rows_all = (size_t)B * Tp;
-    int nbp = 3;
+    int nbp = 2;
     for (int i = 0; i < nact; ++i)
     {
         const TargetBufs &b = tb[active[i]];
@@ -1436,7 +1463,7 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
         {
         case G_FC1:
             pm = &b.fc1_p;
-            t.A = c.xs_p; t.C = c.cat; t.rs0 = c.rs_xs;
+            t.A = c.xs_p; t.C = c.cat; t.rs0 = c.rs_xs; t.rsc = c.rsc_xs;
             t.e0 = b.bn1[0]; t.e1 = b.bn1[1]; t.e2 = b.bn1[2]; t.e3 = b.bn1[3];
             g.N = H; g.K = KX; g.lda = KX; g.ldc = 2 * H; g.a_plane = rows_all * KX;
             break;
@@ -1457,7 +1484,7 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
             break;
         default:
             pm = &b.fc3_p;
-            t.A = c.a2_p; t.C = c.mag; t.rs0 = c.rs_a2;
+            t.A = c.a2_p; t.C = c.mag; t.rs0 = c.rs_a2; t.rsc = c.rsc_a2;
             t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
             t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = ln.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
             g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0; g.a_plane = rows_all * H;
@@ -1468,9 +1495,9 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
         t.bo2[0] = pm->o2[0]; t.bo2[1] = pm->o2[1];
         nbp = pm->nbp; // the same for every target (all_q at create)
     }
-    // 256 x 256 tiles (half the L2 traffic per flop) when they fill the chip; fp32 weights (three planes) do not fit LDS there
+    // 256 x 256 tiles (half the L2 traffic per flop) when they fill the chip
     const int blocks_big = (g.N / 256) * (g.M / 256) * nact;
-    const bool big = nbp < 3 && g.N % 256 == 0 && blocks_big >= 224;
+    const bool big = g.N % 256 == 0 && blocks_big >= 224;
     const int bm = big ? 256 : 128;
     const dim3 grid((unsigned)round_up((g.N / bm) * (g.M / bm), 8), 1, nact), block(big ? 1024 : 256);
     const size_t lds = big ? gp_lds_bytes(4, 4, nbp) : gp_lds_bytes(2, 2, nbp);
@@ -1478,8 +1505,7 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);           \
     else if (big) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 4, 4>), grid, block, lds, st, g);                  \
     else if (nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 2, 2>), grid, block, lds, st, g);             \
-    else if (nbp == 2) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 2>), grid, block, lds, st, g);             \
-    else hipLaunchKernelGGL((gemm_planes_kernel<MODE, 3, 2, 2>), grid, block, lds, st, g);
+    else hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 2>), grid, block, lds, st, g);
     switch (mode)
     {
     case G_FC1: UMX_GP(G_FC1) break;

@@ -17,6 +17,7 @@
 // tile k+1 while tile k is multiplied), double-buffered LDS, one barrier per K tile.
 // Algorithmic flops per 60 s segment: 453.17 GFLOP.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace umx
@@ -83,72 +84,120 @@ __device__ __forceinline__ float4 scale_shift(float4 a, float4 sc, float4 mn)
 // Register budget of the two-slot pipeline (engine.hip): two GEMM blocks (136 VGPRs allocated) must fit a CU
 // beside two 8-wave LSTM workgroups of the other slot (104 each): 2 x 104 + 2 x 136 = 480 <= 512 per SIMD lane.
 // An LSTM kernel above 120 VGPRs halves the overlapped GEMMs' occupancy (measured: 0.9 -> 2.2 ms).
-// Epilogue shared by the fp32-MFMA and the bf16x3 kernels: lane owns column n, rows (r&3) + 8*(r>>2) + 4*lh of
-// each 32x32 accumulator tile (the layout of both v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16).
+// tanh for the fc1 epilogue (inference.cpp:99): |x| < 0.5 an odd minimax polynomial through x^11 (9e-8 relative), else
+// (1 - e) / (1 + e), e = exp(-2|x|) from v_exp_f32 / v_rcp_f32 (no cancellation there: 1 - e >= 0.63); <= 3e-7 relative
+// overall, branch-free, ~18 instructions (the device library's tanhf: ~45 with a divergent branch per element --
+// 64 elements per thread at the end of every tile, with the matrix pipe idle).
+__device__ __forceinline__ float tanh_epi(float x)
+{
+    const float ax = fabsf(x), u = x * x;
+    const float e = __builtin_amdgcn_exp2f(ax * -2.88539008177792681f); // exp(-2|x|)
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    float q = fmaf(u, -0.006946978159248829f, 0.021472707390785217f);
+    q = fmaf(u, q, -0.05393378809094429f);
+    q = fmaf(u, q, 0.1333322674036026f);
+    q = fmaf(u, q, -0.3333333134651184f);
+    const float small = ax * fmaf(u, q, 1.0f);
+    return copysignf(ax < 0.5f ? small : big, x);
+}
+
+// a / b for a divisor known per column: q = a * (1/b) corrected once with the exact remainder (Markstein): the
+// correctly rounded quotient, i.e. bit-identical to the IEEE division the reference's expression performs
+// (inference.cpp:94-95), in 3 instructions instead of the ~11 of v_div_scale / v_div_fmas / v_div_fixup.
+__device__ __forceinline__ float div_by(float a, float b, float rcp_b)
+{
+    const float q = a * rcp_b;
+    return fmaf(fmaf(-q, b, a), rcp_b, q);
+}
+
+// Epilogue shared by the fp32-MFMA, the bf16x3 and the plane kernels: lane owns column n, rows
+// (r&3) + 8*(r>>2) + 4*lh of each 32x32 accumulator tile (the layout of v_mfma_f32_32x32x{2_f32,16_bf16,16_f16}).
+// Everything that does not depend on the element is hoisted: the rows of a block belong to ONE track lane (Tp_lane
+// is a multiple of the tile height), so the lane index and its offsets are scalars; 32-bit element offsets; groups
+// of four rows separated by compiler fences so that the loads of later rows do not pile up in registers (this
+// epilogue runs with all 16 waves of a 256 x 256 block at once and nothing to overlap it with).
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmArgs &args, int m0, int n0, int wm, int wn,
                                               int lr, int lh, const floatx16 &acc00, const floatx16 &acc01,
                                               const floatx16 &acc10, const floatx16 &acc11)
 {
+    int f0 = m0;          // frame of row m0 inside its track lane
+    unsigned lo = 0, ld = 0; // element offsets of that lane in the magnitude / debug outputs
+    if (MODE == G_FC3 && args.Tp_lane)
+    {
+        const int ln = __builtin_amdgcn_readfirstlane(m0 / args.Tp_lane);
+        f0 = m0 - ln * args.Tp_lane;
+        lo = (unsigned)(ln * args.mag_lane);
+        ld = (unsigned)(ln * args.dbg_lane);
+    }
+    // fc3 only (dead code elsewhere): buffer resources of the magnitude output, the mix magnitude and the debug tap
+    const int lanes = args.Tp_lane ? args.M / args.Tp_lane : 1;
+    const int mag_bytes = MODE == G_FC3 ? (int)((args.Tp_lane ? (size_t)lanes * args.mag_lane : (size_t)2 * args.T * NBINS) * 4) : 0;
+    const int dbg_bytes = MODE == G_FC3 && tg.dbg ? (int)((args.Tp_lane ? (size_t)lanes * args.dbg_lane : (size_t)args.T * NOUT) * 4) : 0;
+    const __amdgpu_buffer_rsrc_t rs_mag = __builtin_amdgcn_make_buffer_rsrc(tg.C, 0, mag_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == G_FC3 ? tg.aux : tg.C), 0, mag_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dbg = __builtin_amdgcn_make_buffer_rsrc(MODE == G_FC3 && tg.dbg ? tg.dbg : tg.C, 0, dbg_bytes, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
     {
         const int n = n0 + wn * 64 + ni * 32 + lr;
-        float rm = 0.f, sd = 1.f, gw = 1.f, gb = 0.f, osc = 1.f, omn = 0.f;
+        float rm = 0.f, sd = 1.f, rsd = 1.f, gw = 1.f, gb = 0.f, osc = 1.f, omn = 0.f;
         if (MODE == G_IH)
             gb = tg.e0[n];
         else
         {
             rm = tg.e0[n];
             sd = sqrtf(tg.e1[n] + 1e-5f); // inference.cpp:94-95
+            rsd = 1.0f / sd;
             gw = tg.e2[n];
             gb = tg.e3[n];
         }
+        unsigned col = (unsigned)n; // element offset of (row 0 of the block, column n)
         if (MODE == G_FC3)
         {
             osc = tg.q0[n];
             omn = tg.q1[n];
+            const int c = n >= NBINS ? 1 : 0;
+            col = lo + (unsigned)(c * args.T) * NBINS + (unsigned)(n - c * NBINS);
         }
+        // fc3: frames >= T (M padding) and columns >= NOUT (N padding) are dropped by the buffer range check (their
+        // byte offset is replaced by one past the end), and so is the whole debug tap when there is none (a resource of
+        // zero records): no branch and no 64-bit address arithmetic per element
+        const bool col_ok = MODE != G_FC3 || n < NOUT;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int rq = 0; rq < 4; ++rq)
             {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float y = mi == 0 ? (ni == 0 ? acc00[r] : acc01[r]) : (ni == 0 ? acc10[r] : acc11[r]);
-                if (MODE == G_IH)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
                 {
-                    tg.C[(size_t)m * args.ldc + n] = y + gb; // lstm.cpp:132-135: W_ih x + b_ih
-                }
-                else
-                {
-                    y = ((y - rm) / sd) * gw + gb; // batchnorm, inference.cpp:93-97 order
-                    if (MODE == G_FC1)
-                        tg.C[(size_t)m * args.ldc + n] = tanhf(y);
-                    else if (MODE == G_FC2)
-                        tg.C[(size_t)m * args.ldc + n] = fmaxf(y, 0.f);
-                    else if (n < NOUT)
+                    const int r = 4 * rq + j;
+                    const int ml = wm * 64 + mi * 32 + j + 8 * rq + 4 * lh; // row inside the block
+                    float y = mi == 0 ? (ni == 0 ? acc00[r] : acc01[r]) : (ni == 0 ? acc10[r] : acc11[r]);
+                    if (MODE == G_IH)
+                        tg.C[(size_t)(m0 + ml) * args.ldc + n] = y + gb; // lstm.cpp:132-135: W_ih x + b_ih
+                    else
                     {
-                        int f = m;
-                        size_t lo = 0, ld = 0;
-                        if (args.Tp_lane)
+                        y = div_by(y - rm, sd, rsd) * gw + gb; // batchnorm, inference.cpp:93-97 order
+                        if (MODE == G_FC1)
+                            tg.C[(size_t)(m0 + ml) * args.ldc + n] = tanh_epi(y);
+                        else if (MODE == G_FC2)
+                            tg.C[(size_t)(m0 + ml) * args.ldc + n] = fmaxf(y, 0.f);
+                        else
                         {
-                            const int ln = m / args.Tp_lane;
-                            f = m - ln * args.Tp_lane;
-                            lo = (size_t)ln * args.mag_lane;
-                            ld = (size_t)ln * args.dbg_lane;
-                        }
-                        if (f < args.T)
-                        {
+                            const int f = f0 + ml;
+                            const bool ok = col_ok && f < args.T;
                             y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
-                            if (tg.dbg)
-                                tg.dbg[ld + (size_t)f * NOUT + n] = y;
-                            const int c = n >= NBINS ? 1 : 0, b = n - c * NBINS;
-                            const size_t idx = lo + ((size_t)c * args.T + f) * NBINS + b;
-                            tg.C[idx] = y * tg.aux[idx]; // inference.cpp:175-183
+                            const unsigned off = ok ? (col + (unsigned)f * NBINS) * 4u : 0xfffffff0u;
+                            const unsigned offd = ok ? (ld + (unsigned)f * NOUT + (unsigned)n) * 4u : 0xfffffff0u;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_dbg, offd, 0, 0);
+                            const float mix = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_aux, off, 0, 0));
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y * mix), rs_mag, off, 0, 0); // inference.cpp:175-183
                         }
                     }
                 }
+                asm volatile("" ::: "memory");
             }
     }
 }
