@@ -314,6 +314,27 @@ def test_device_resident_track_equals_host_split_and_shift(pkg, small):
     eng.stream_reset()
 
 
+def test_fused_wiener_istft_equals_the_unfused_kernels_bitwise(pkg, model_small, monkeypatch):
+    """csrc/wiener_istft.h (gains + filter + inverse STFT frame in one kernel, all-source statistics kernel) must give
+    the bits of the three-kernel Wiener path followed by the separate inverse STFT (UMX_WIENER=unfused), with and
+    without the EM step (BASELINE config 2), including the y tap."""
+    import torch
+    torch.zeros(1).cuda()
+    path, om, targets = model_small
+    N = 40 * 1024
+    wave = pkg.ggml.synth_audio(N, 77)
+    for flags in (pkg.FLAG_DEBUG_TAPS, pkg.FLAG_DEBUG_TAPS | pkg.FLAG_NO_WIENER):
+        res = {}
+        for mode in ("unfused", "fused"):
+            monkeypatch.setenv("UMX_WIENER", mode)
+            eng = pkg.Engine(targets, 128, N)
+            res[mode] = (eng.infer_segment(wave, flags), [eng.tap("y", t) for t in range(4)])
+            eng.close()
+        for t in range(4):
+            assert np.array_equal(res["fused"][0][t], res["unfused"][0][t])
+            assert np.array_equal(res["fused"][1][t], res["unfused"][1][t])
+
+
 def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_path):
     """The dense stack runs on the bf16 matrix cores (fp32 activations split into three bf16 terms, fp32 accumulation):
     gemm="bf16x3" splits while it stages every tile (csrc/gemm_bf16x3.h, the single-track default), gemm="planes" consumes

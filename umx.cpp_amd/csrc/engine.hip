@@ -30,6 +30,7 @@
 #include "track_kernels.h"
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
+#include "wiener_istft.h"
 
 using namespace umx;
 
@@ -104,7 +105,7 @@ struct Lane
 {
     TargetAct ta[4];
     float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
-    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr;
+    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr, *Rc = nullptr;
     unsigned *maxabs = nullptr;
 };
 
@@ -291,6 +292,7 @@ struct umx_hip_ctx
              unsigned create_flags, int n_tracks);
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
     bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
+    bool wiener_fused = true;     // wiener_istft.h (UMX_WIENER=unfused: the three-kernel path + separate inverse STFT)
     bool gemm_planes = false;     // ... with both operands pre-split / re-encoded as bf16 planes and LDS-DMA staging (gemm_planes.h)
     void launch_split(Lane &ln, int nl, hipStream_t st, int which, const int *active, int nact);
     void launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
@@ -497,6 +499,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     };
 
     gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // the bf16 matrix cores are the default
+    if (const char *e = getenv("UMX_WIENER")) // A/B switch: the unfused three-kernel Wiener path + separate inverse STFT
+        wiener_fused = std::string(e) != "unfused";
     // gemm_planes.h for track-batched contexts (large tiles over all lanes); gemm_bf16x3.h for the single-track,
     // latency-optimised context, whose pipeline overlaps small GEMM blocks with two co-resident LSTM grids (the register
     // and LDS budget of DESIGN 4.2 was tuned for exactly that kernel).  Either can be forced.
@@ -985,9 +989,12 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 return rc;
             if (int rc = dalloc(&L.frames, (size_t)4 * T * NFFT))
                 return rc;
-            if (int rc = dalloc(&L.wpart, (size_t)4 * nbatch * NBINS * 9))
+            const size_t nchunk = (size_t)(T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+            if (int rc = dalloc(&L.wpart, std::max((size_t)4 * nbatch * NBINS * 9, nchunk * 4 * 5 * NBINS)))
                 return rc;
             if (int rc = dalloc(&L.R, (size_t)4 * NBINS * 8))
+                return rc;
+            if (int rc = dalloc(&L.Rc, (size_t)4 * NBINS * 4))
                 return rc;
             if (int rc = dalloc(&L.maxabs, 4))
                 return rc;
@@ -1070,6 +1077,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC3, BQ_U16>)};
         for (const void *fn : bxs)
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
+        UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WI_LDS_BYTES));
+        UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WI_LDS_BYTES));
 #define UMX_GP_ATTR(MODE)                                                                                              \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 2))); \
@@ -1589,24 +1598,50 @@ int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const
         WienerMags wm;
         for (int s = 0; s < 4; ++s)
             wm.m[s] = L.ta[s].mag;
-        if (flags & UMX_FLAG_NO_WIENER)
+        if (!wiener_fused)
         {
-            const size_t nel = (size_t)2 * T * NBINS;
-            hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, L.spec, wm, T, L.y);
+            if (flags & UMX_FLAG_NO_WIENER)
+            {
+                const size_t nel = (size_t)2 * T * NBINS;
+                hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, L.spec, wm, T, L.y);
+            }
+            else
+            {
+                hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.wpart,
+                                   nbatch);
+                hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, nbatch, L.R);
+                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
+            }
         }
-        else
+        else if (!(flags & UMX_FLAG_NO_WIENER))
         {
-            hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.wpart,
-                               nbatch);
-            hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, nbatch, L.R);
-            hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
+            const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+            hipLaunchKernelGGL(wiener_stats4_kernel, dim3((NBINS + 63) / 64, nchunk), dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
+            hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, T, L.Rc);
         }
     }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
     for (int ln = 0; ln < nb; ++ln)
         if (audio_dev[ln])
-            hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, sl.lane[ln].y, T, window, nw, tw1, tw2,
-                               sl.lane[ln].frames);
+        {
+            Lane &L = sl.lane[ln];
+            if (!wiener_fused)
+                hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, L.y, T, window, nw, tw1, tw2, L.frames);
+            else
+            {
+                // gains + filter + inverse STFT frame in one pass (wiener_istft.h); y reaches HBM only for the debug tap
+                WienerMags wm;
+                for (int s = 0; s < 4; ++s)
+                    wm.m[s] = L.ta[s].mag;
+                float2 *ydbg = dbg ? L.y : nullptr;
+                if (flags & UMX_FLAG_NO_WIENER)
+                    hipLaunchKernelGGL((wiener_istft_kernel<false>), dim3(T), dim3(WI_THREADS), WI_LDS_BYTES, st, L.spec, wm, T, L.maxabs, L.Rc, window, nw,
+                                       tw1, tw2, L.frames, ydbg);
+                else
+                    hipLaunchKernelGGL((wiener_istft_kernel<true>), dim3(T), dim3(WI_THREADS), WI_LDS_BYTES, st, L.spec, wm, T, L.maxabs, L.Rc, window, nw,
+                                       tw1, tw2, L.frames, ydbg);
+            }
+        }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
     for (int ln = 0; ln < nb; ++ln)
         if (audio_dev[ln])

@@ -84,11 +84,12 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16])
 // In: v[r] = input[j + 256*r] for this thread j = threadIdx.x (256 threads).
 // Out: buf[fft_pad(k)] = transform bin k, natural order, visible after the final barrier.
 // Unscaled in both directions (dsp.cpp:136 Unscaled flag).
+// j: the thread's index inside the 256-thread group that owns buf (several groups of one workgroup may transform
+// side by side, each in its own buffer; the barriers are workgroup-wide, so every group must make the same calls).
 template <bool INV>
 __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const float2 *__restrict__ tw1,
-                                        const float2 *__restrict__ tw2)
+                                        const float2 *__restrict__ tw2, int j)
 {
-    const int j = threadIdx.x;
     // pass 0 (Ns = 1): no twiddles
     fft16<INV>(v);
 #pragma unroll
@@ -132,6 +133,13 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const floa
             buf[fft_pad(j + 256 * q)] = v[q];
     }
     __syncthreads();
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const float2 *__restrict__ tw1,
+                                        const float2 *__restrict__ tw2)
+{
+    fft4096<INV>(v, buf, tw1, tw2, (int)threadIdx.x);
 }
 
 } // namespace umx

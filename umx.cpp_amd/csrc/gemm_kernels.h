@@ -101,15 +101,6 @@ __device__ __forceinline__ float tanh_epi(float x)
     return copysignf(ax < 0.5f ? small : big, x);
 }
 
-// a / b for a divisor known per column: q = a * (1/b) corrected once with the exact remainder (Markstein): the
-// correctly rounded quotient, i.e. bit-identical to the IEEE division the reference's expression performs
-// (inference.cpp:94-95), in 3 instructions instead of the ~11 of v_div_scale / v_div_fmas / v_div_fixup.
-__device__ __forceinline__ float div_by(float a, float b, float rcp_b)
-{
-    const float q = a * rcp_b;
-    return fmaf(fmaf(-q, b, a), rcp_b, q);
-}
-
 // Epilogue shared by the fp32-MFMA, the bf16x3 and the plane kernels: lane owns column n, rows
 // (r&3) + 8*(r>>2) + 4*lh of each 32x32 accumulator tile (the layout of v_mfma_f32_32x32x{2_f32,16_bf16,16_f16}).
 // Everything that does not depend on the element is hoisted: the rows of a block belong to ONE track lane (Tp_lane

@@ -1,0 +1,121 @@
+// wiener_istft.h -- Wiener gains + filter (wiener.cpp:270-425) fused with the inverse STFT frame (dsp.cpp:229-258):
+// the filtered spectrograms y [4][2][T][2049] complex (339 MB per 60 s segment, written by one kernel and read back by
+// the next) never touch HBM.
+//
+// One workgroup per frame, 1024 threads.
+//   phase 1  thread t handles bins b = t + 1024 q (2049 bins, 2-3 per thread): loads the mixture (2 channels), the four
+//            target magnitudes (x 2 channels) and the four R (16 bytes each), forms what does not depend on the output
+//            source -- mixture over max_abs, the four PSDs, the inverse of Cxx (wiener.cpp:270-341) -- and then, for each
+//            source, y_s = G_s x (wiener.cpp:343-400), written straight into the INPUT of that source's inverse FFT in
+//            LDS: one complex 4096-point transform per source carries the left channel in its real and the right channel
+//            in its imaginary part (stft_kernels.h), so bin b fills two slots:
+//                in[b]        = L[b] + i R[b]                  b <= 2048
+//                in[4096 - b] = conj(L[b]) + i conj(R[b])      0 < b < 2048
+//   phase 2  the four 256-thread groups transform the four sources side by side (4 x 34 KB of LDS), apply the
+//            reference's per-sample weight (dsp.cpp:248-256) and store the frames.
+// 16 waves per CU hide the latencies of both phases (a 256-thread version holding nine bins per thread in registers ran
+// at one wave per SIMD and was no faster than the two kernels it replaced).  Per frame: 98 KB of spectrogram /
+// magnitudes and 131 KB of R (L2-resident) in, 131 KB of frames out, against 229 + 131 KB in and 131 + 131 KB out.
+// WIENER = false is BASELINE config 2: y_s = mag_s * exp(i arg X) (wiener.cpp:96-109 only).
+#pragma once
+#include "stft_kernels.h"
+#include "wiener_kernels.h"
+
+namespace umx
+{
+
+constexpr int WI_THREADS = 1024;
+constexpr int WI_LDS_BYTES = 4 * FFT_LDS_ELEMS * (int)sizeof(float2); // 139,264
+
+template <bool WIENER>
+__global__ __launch_bounds__(WI_THREADS) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
+                                                                  const unsigned *__restrict__ maxabs_bits,
+                                                                  const float *__restrict__ Rc, const float *__restrict__ window,
+                                                                  const float *__restrict__ nw, const float2 *__restrict__ tw1,
+                                                                  const float2 *__restrict__ tw2, float2 *__restrict__ frames,
+                                                                  float2 *__restrict__ y_dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [4][FFT_LDS_ELEMS]
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+    {
+        const int b = tid + WI_THREADS * q;
+        if (b > NFFT / 2)
+            break;
+        const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
+        const float2 X0 = spec[i0], X1 = spec[i1];
+        float m0[4], m1[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            m0[s] = mags.m[s][i0];
+            m1[s] = mags.m[s][i1];
+        }
+        WienerBin wb;
+        float4 rc[4];
+        float2 p0, p1;
+        if (WIENER)
+        {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                rc[s] = *reinterpret_cast<const float4 *>(Rc + ((size_t)s * NBINS + b) * 4);
+            wiener_bin_setup(X0, X1, m0, m1, rc, max_abs, rmax, wb);
+        }
+        else
+        {
+            p0 = unit_phasor(X0);
+            p1 = unit_phasor(X1);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            float2 o[2];
+            if (WIENER)
+                wiener_bin_apply(wb, s, rc[s], max_abs, o);
+            else
+            {
+                o[0] = make_float2(m0[s] * p0.x, m0[s] * p0.y);
+                o[1] = make_float2(m1[s] * p1.x, m1[s] * p1.y);
+            }
+            if (y_dbg)
+            {
+                y_dbg[(((size_t)s * 2 + 0) * T + f) * NBINS + b] = o[0];
+                y_dbg[(((size_t)s * 2 + 1) * T + f) * NBINS + b] = o[1];
+            }
+            float2 a = o[0], bb = o[1];
+            if (b == 0 || b == NFFT / 2) // a real inverse FFT ignores Im of DC / Nyquist
+            {
+                a.y = 0.f;
+                bb.y = 0.f;
+            }
+            float2 *buf = wi_buf + s * FFT_LDS_ELEMS;
+            buf[fft_pad(b)] = make_float2(a.x - bb.y, a.y + bb.x); // a + i b
+            if (b > 0 && b < NFFT / 2)
+                buf[fft_pad(NFFT - b)] = make_float2(a.x + bb.y, bb.x - a.y); // conj(a) + i conj(b)
+        }
+    }
+    __syncthreads();
+    const int g = tid >> 8, j = tid & 255; // source, thread of its transform
+    float2 *buf = wi_buf + g * FFT_LDS_ELEMS;
+    float2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        v[r] = buf[fft_pad(j + 256 * r)];
+    __syncthreads();
+    fft4096<true>(v, buf, tw1, tw2, j);
+    float2 *dst = frames + ((size_t)g * T + f) * NFFT;
+    const size_t start = (size_t)f * HOP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        const int i = j + 256 * r;
+        const float2 z = buf[fft_pad(i)];
+        const float w = window[i];
+        const float den = nw[start + i] + 1e-8f;
+        dst[i] = make_float2(z.x * w * 1.0f / float(NFFT) / den, z.y * w * 1.0f / float(NFFT) / den); // dsp.cpp:248-256
+    }
+}
+
+} // namespace umx

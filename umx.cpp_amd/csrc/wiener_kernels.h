@@ -189,6 +189,229 @@ __global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round-2 forms (the three kernels above remain as the unfused reference path, UMX_WIENER=unfused).
+//
+// R_j is Hermitian BIT FOR BIT: R10 accumulates y1 conj(y0), whose real part is the same two products in the same
+// order as R01's and whose imaginary part is its exact negation; R00 and R11 have an exactly zero imaginary part
+// (-ab + ba).  So four floats per (source, bin) carry everything: {R00, Re R01, Im R01, R11}.
+//
+//   wiener_stats4_kernel   one thread = one bin x one batch of the reference (wiener.cpp:212-258) x ALL FOUR sources,
+//                          frames accumulated in the reference's order (same bits as the per-source kernel above):
+//                          the mixture spectrogram and its unit phasor are read / formed once instead of four times,
+//                          and the loads of the NEXT eight frames are in flight while eight are accumulated (the
+//                          per-source kernel had one frame in flight per thread and ~1.5 waves per SIMD to hide the
+//                          latency behind: 1.5 TB/s).  64-thread workgroups so that the 13 x 33 of them cover the chip.
+//   wiener_finish4_kernel  R_j(b) = (batch sums in batch order) / (eps + sum v)  -> Rc [4][2049][4]
+//   wiener_istft_kernel    (wiener_istft.h) gains + filter + inverse STFT frame in one pass: y never goes to HBM.
+constexpr int WIENER_CHUNK = WIENER_BATCH; // frames per thread of wiener_stats4_kernel (a divisor of WIENER_BATCH)
+static_assert(WIENER_BATCH % WIENER_CHUNK == 0, "chunks must not straddle the reference's batches");
+constexpr int WIENER_PF = 8;               // frames per prefetch group
+
+struct WienerFrame // what one frame contributes to one bin: mixture (2 channels) and 4 x 2 magnitudes
+{
+    float2 X0, X1;
+    float m0[4], m1[4];
+};
+__device__ __forceinline__ void wiener_frame_load(WienerFrame &w, const float2 *__restrict__ spec, const WienerMags &mags, int T,
+                                                  int f, int b)
+{
+    const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
+    w.X0 = spec[i0];
+    w.X1 = spec[i1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+    {
+        w.m0[s] = mags.m[s][i0];
+        w.m1[s] = mags.m[s][i1];
+    }
+}
+
+// grid (ceil(B/64), nchunk), 64 threads.  part: [nchunk][4 sources][5][2049] = R00, Re R01, Im R01, R11, sum v (bin fastest)
+__global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
+                                                           const unsigned *__restrict__ maxabs_bits,
+                                                           float *__restrict__ part)
+{
+    const int b = min(blockIdx.x * 64 + threadIdx.x, NBINS - 1), chunk = blockIdx.y; // surplus lanes repeat the last bin
+    const float max_abs = wiener_max_abs(maxabs_bits), rmax = 1.0f / max_abs;
+    const int f0 = chunk * WIENER_CHUNK, f1 = min(T, f0 + WIENER_CHUNK);
+    float r00[4] = {0.f, 0.f, 0.f, 0.f}, r01x[4] = {0.f, 0.f, 0.f, 0.f}, r01y[4] = {0.f, 0.f, 0.f, 0.f},
+          r11[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto accumulate = [&](const WienerFrame &w) {
+        const float2 p0 = unit_phasor(w.X0), p1 = unit_phasor(w.X1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            // wiener_y0 with the division by max_abs as an exact 3-instruction quotient (div_by, common.h)
+            const float2 y0 = make_float2(div_by(w.m0[s] * p0.x, max_abs, rmax), div_by(w.m0[s] * p0.y, max_abs, rmax));
+            const float2 y1 = make_float2(div_by(w.m1[s] * p1.x, max_abs, rmax), div_by(w.m1[s] * p1.y, max_abs, rmax));
+            // v = 1/2 sum_c (Re + Im)^2   wiener.cpp:187-202 (F5)
+            const float ra = y0.x + y0.y, rb = y1.x + y1.y;
+            float sum = 0.f;
+            sum += (ra * ra) + (0.f * 0.f);
+            sum += (rb * rb) + (0.f * 0.f);
+            wsum[s] += sum / 2;
+            // calculateCovariance wiener.cpp:435-478: a * conj(b); only the independent entries
+            const float2 q00 = cmul(y0, cconj(y0)), q01 = cmul(y0, cconj(y1)), q11 = cmul(y1, cconj(y1));
+            r00[s] += (0.f + q00.x);
+            r01x[s] += (0.f + q01.x);
+            r01y[s] += (0.f + q01.y);
+            r11[s] += (0.f + q11.x);
+        }
+    };
+    WienerFrame cur[WIENER_PF], nxt[WIENER_PF];
+#pragma unroll
+    for (int k = 0; k < WIENER_PF; ++k)
+        wiener_frame_load(cur[k], spec, mags, T, min(f0 + k, f1 - 1), b);
+    for (int f = f0; f < f1; f += WIENER_PF)
+    {
+#pragma unroll
+        for (int k = 0; k < WIENER_PF; ++k) // the next group is in flight while this one is accumulated
+            wiener_frame_load(nxt[k], spec, mags, T, min(f + WIENER_PF + k, f1 - 1), b);
+#pragma unroll
+        for (int k = 0; k < WIENER_PF; ++k)
+            if (f + k < f1)
+                accumulate(cur[k]);
+#pragma unroll
+        for (int k = 0; k < WIENER_PF; ++k)
+            cur[k] = nxt[k];
+    }
+    if (blockIdx.x * 64 + threadIdx.x >= NBINS)
+        return;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+    {
+        float *o = part + ((size_t)(chunk * 4 + s) * 5) * NBINS + b;
+        o[0] = r00[s];
+        o[NBINS] = r01x[s];
+        o[2 * NBINS] = r01y[s];
+        o[3 * NBINS] = r11[s];
+        o[4 * NBINS] = wsum[s];
+    }
+}
+
+// grid (ceil(B/256), 4).  Rc: [4][2049][4] = {R00, Re R01, Im R01, R11}
+__global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__restrict__ part, int T, float *__restrict__ Rc)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
+    if (b >= NBINS)
+        return;
+    constexpr int CPB = WIENER_BATCH / WIENER_CHUNK;
+    const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float weight = WIENER_EPS; // wiener.cpp:210
+    for (int c0 = 0; c0 < nchunk; c0 += CPB)
+    {
+        float bs[5] = {0.f, 0.f, 0.f, 0.f, 0.f}; // one batch of the reference = CPB chunks, in frame order
+        for (int c = c0; c < min(nchunk, c0 + CPB); ++c)
+        {
+            const float *p = part + ((size_t)(c * 4 + src) * 5) * NBINS + b;
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                bs[i] += p[(size_t)i * NBINS];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc[i] += bs[i]; // wiener.cpp:243  R += batch sum
+        weight += bs[4];     // wiener.cpp:247-253
+    }
+    *reinterpret_cast<float4 *>(Rc + ((size_t)src * NBINS + b) * 4) =
+        make_float4(acc[0] / weight, acc[1] / weight, acc[2] / weight, acc[3] / weight); // wiener.cpp:259-269
+}
+
+// The per-bin part of wiener_apply_kernel, split in two so that the fused kernel can hold many bins in registers:
+// WienerBin = everything that does not depend on the source whose output is being formed.
+struct WienerBin
+{
+    // inverse of Cxx (wiener.cpp:54-84).  Cxx = sum_s (sqrt(eps) I + v_s R_s) is Hermitian bit for bit like the R_s
+    // (real diagonal, C10 = conj(C01) exactly), its determinant is exactly real, and so its inverse is Hermitian too:
+    // four floats {Ci00, Re Ci01, Im Ci01, Ci11}
+    float ci00, ci01x, ci01y, ci11;
+    float2 x0, x1; // mixture / max_abs
+    float v[4];    // source PSDs
+};
+
+__device__ __forceinline__ void wiener_expand(float4 rc, float2 (&Rr)[2][2])
+{
+    Rr[0][0] = make_float2(rc.x, 0.f);
+    Rr[0][1] = make_float2(rc.y, rc.z);
+    Rr[1][0] = make_float2(rc.y, -rc.z);
+    Rr[1][1] = make_float2(rc.w, 0.f);
+}
+
+__device__ __forceinline__ void wiener_bin_setup(float2 X0, float2 X1, const float (&m0)[4], const float (&m1)[4],
+                                                 const float4 (&rc)[4], float max_abs, float rmax, WienerBin &w)
+{
+    const float reg = sqrtf(WIENER_EPS); // wiener.cpp:165
+    w.x0 = make_float2(div_by(X0.x, max_abs, rmax), div_by(X0.y, max_abs, rmax)); // wiener.cpp:118-130
+    w.x1 = make_float2(div_by(X1.x, max_abs, rmax), div_by(X1.y, max_abs, rmax));
+    const float2 p0 = unit_phasor(X0), p1 = unit_phasor(X1);
+    float2 C[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+    {
+        const float2 ya = make_float2(div_by(m0[s] * p0.x, max_abs, rmax), div_by(m0[s] * p0.y, max_abs, rmax));
+        const float2 yb = make_float2(div_by(m1[s] * p1.x, max_abs, rmax), div_by(m1[s] * p1.y, max_abs, rmax));
+        const float ra = ya.x + ya.y, rb = yb.x + yb.y;
+        float sum = 0.f;
+        sum += (ra * ra) + (0.f * 0.f);
+        sum += (rb * rb) + (0.f * 0.f);
+        w.v[s] = sum / 2;
+        float2 Rr[2][2];
+        wiener_expand(rc[s], Rr);
+#pragma unroll
+        for (int c1 = 0; c1 < 2; ++c1)
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+            { // wiener.cpp:307-325: Cxx += reg(c1,c2) + v * R   (F6: once per source)
+                const float2 term = make_float2((c1 == c2 ? reg : 0.f) + w.v[s] * Rr[c1][c2].x, 0.f + w.v[s] * Rr[c1][c2].y);
+                C[c1][c2].x += term.x;
+                C[c1][c2].y += term.y;
+            }
+    }
+    // invert4D wiener.cpp:54-84
+    const float2 det = csub(cmul(C[0][0], C[1][1]), cmul(C[0][1], C[1][0]));
+    const float nrm = det.x * det.x + det.y * det.y;
+    const float2 invDet = make_float2(det.x / nrm, -det.y / nrm);
+    const float2 nInv = make_float2(-invDet.x, -invDet.y);
+    const float2 i00 = cmul(invDet, C[1][1]), i01 = cmul(nInv, C[0][1]), i11 = cmul(invDet, C[0][0]);
+    w.ci00 = i00.x;
+    w.ci01x = i01.x;
+    w.ci01y = i01.y;
+    w.ci11 = i11.x;
+}
+
+// y_s = G_s x * max_abs for one source (wiener.cpp:343-400)
+__device__ __forceinline__ void wiener_bin_apply(const WienerBin &w, int s, float4 rc, float max_abs, float2 (&o)[2])
+{
+    const float vs = s == 0 ? w.v[0] : s == 1 ? w.v[1] : s == 2 ? w.v[2] : w.v[3]; // selects: w stays in registers
+    float2 Rr[2][2];
+    wiener_expand(rc, Rr);
+    const float2 Ci[2][2] = {{make_float2(w.ci00, 0.f), make_float2(w.ci01x, w.ci01y)},
+                             {make_float2(w.ci01x, -w.ci01y), make_float2(w.ci11, 0.f)}};
+    float2 g[2][2];
+#pragma unroll
+    for (int c1 = 0; c1 < 2; ++c1)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+        {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int c3 = 0; c3 < 2; ++c3)
+                acc = cadd(acc, cmul(Rr[c1][c3], Ci[c3][c2]));
+            g[c1][c2] = make_float2(acc.x * vs, acc.y * vs);
+        }
+    o[0] = make_float2(0.f, 0.f);
+    o[1] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int c1 = 0; c1 < 2; ++c1) // wiener.cpp:381-400
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+            o[c2] = cadd(o[c2], cmul(g[c2][c1], c1 == 0 ? w.x0 : w.x1));
+    o[0] = make_float2(o[0].x * max_abs, o[0].y * max_abs);
+    o[1] = make_float2(o[1].x * max_abs, o[1].y * max_abs);
+}
+
 // "no Wiener" configuration (BASELINE config 2): y_j = mag_j * exp(i arg X)  (wiener.cpp:96-109 only)
 __global__ __launch_bounds__(256) void mixphase_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
                                                        float2 *__restrict__ y)
