@@ -34,6 +34,7 @@
 // fallback (and cross-check) that needs no co-residency.
 #pragma once
 #include "gemm_bf16x3.h"
+#include "gemm_planes.h" // split2_f16
 #include "lstm_kernels.h"
 
 namespace umx
@@ -164,7 +165,16 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 for (int j = 0; j < 8; ++j)
                     wv[j] = WQ ? (float)a.Wq[base + (size_t)j * 64] - 128.0f : whh_at(a.W, a.Wq, a.wsc[wchain], a.wof[wchain], base + (size_t)j * 64);
                 uint4 p1, p2, p3;
-                split3(wv, p1, p2, p3); // WQ: wv is an integer in [-128, 127] -> p1 exact, p2 = p3 = 0
+                if (WQ) // an integer in [-128, 127]: exact in ONE fp16 plane
+                {
+                    f16x8 hw;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        hw[j] = (_Float16)wv[j];
+                    p1 = __builtin_bit_cast(uint4, hw);
+                }
+                else
+                    split3(wv, p1, p2, p3);
                 Wf[mt][ks][0] = as_bf16x8(p1);
                 if (!WQ)
                 {
@@ -173,8 +183,15 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 }
             }
     }
-    const bf16x8 ones = as_bf16x8(make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u));
-    const float wsc = a.wsc[wchain], wof2 = a.wof[wchain] + 128.0f * a.wsc[wchain]; // WQ: W h = wsc * A + wof2 * sum(h)
+    // WQ: h travels as TWO fp16 planes of h * 2^14 (h1 = fp16(h'), h2 = fp16(h' - h1): 22 significand bits + the
+    // residual's sign; |h| < 1 so h' < 2^14, and the second plane is a normal fp16 number down to residuals of 2^-28)
+    // against ONE exact fp16 plane of q - 128: two products instead of the three of a bf16 split.  The power of two
+    // comes back out with the scale:  W h = (wsc 2^-14) * sum (q-128) h' + ((wof + 128 wsc) 2^-14) * sum h'
+    constexpr float HSCALE = 16384.0f;
+    const bf16x8 ones = as_bf16x8(WQ ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u)   // fp16 1.0
+                                     : make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u)); // bf16 1.0
+    const float wsc = a.wsc[wchain] * (WQ ? 1.0f / HSCALE : 1.0f),
+                wof2 = (a.wof[wchain] + 128.0f * a.wsc[wchain]) * (WQ ? 1.0f / HSCALE : 1.0f);
 
     // ---- per-(unit, track) cell state of the gate lanes, b_hh of the unit's four gates
     const int unit = slice * 16 + 4 * (w & 3) + q;
@@ -200,8 +217,11 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             hv[j] = (dot_wave && lane_on) ? a.state[st_h + (w * KSW + ks) * 32 + 8 * q + j] : 0.f;
-        uint4 p1, p2, p3;
-        split3(hv, p1, p2, p3);
+        uint4 p1, p2, p3 = make_uint4(0u, 0u, 0u, 0u);
+        if (WQ)
+            split2_f16(hv, HSCALE, p1, p2);
+        else
+            split3(hv, p1, p2, p3);
         hf[ks][0] = as_bf16x8(p1);
         hf[ks][1] = as_bf16x8(p2);
         hf[ks][2] = as_bf16x8(p3);
@@ -341,17 +361,21 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 #define LSTMB_TERM(PW, PH)                                                                                         \
     _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)            \
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[mt][ks][PW], hf[ks][PH], acc[mt], 0, 0, 0);
+#define LSTMB_TERM16(PH)                                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)            \
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[mt][ks][0]),                 \
+                                                         __builtin_bit_cast(f16x8, hf[ks][PH]), acc[mt], 0, 0, 0);
             if (WQ)
             {
-                // smallest terms first
-                LSTMB_TERM(0, 2)
-                LSTMB_TERM(0, 1)
-                LSTMB_TERM(0, 0)
+                // smaller term first
+                LSTMB_TERM16(1)
+                LSTMB_TERM16(0)
 #pragma unroll
-                for (int ph = 2; ph >= 0; --ph)
+                for (int ph = 1; ph >= 0; --ph)
 #pragma unroll
                     for (int ks = 0; ks < KSW; ++ks)
-                        accH = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, hf[ks][ph], accH, 0, 0, 0);
+                        accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, hf[ks][ph]),
+                                                                      accH, 0, 0, 0);
             }
             else
             {
@@ -363,6 +387,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 LSTMB_TERM(0, 0)
             }
 #undef LSTMB_TERM
+#undef LSTMB_TERM16
             if (n < nbp)
             {
                 float4 *pw = part + ((size_t)(((step & 1) * 8 + w) * 4) * 4 + q) * nbp + n;
@@ -427,15 +452,28 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             }
             const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
             const float h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
-            // h split in three bf16 terms; the odd unit of the pair sits 16 lanes up in this wave
-            const unsigned b1 = cvt_pk_bf16(h, 0.f) & 0xffffu;
-            const float r1 = h - __uint_as_float(b1 << 16);
-            const unsigned b2 = cvt_pk_bf16(r1, 0.f) & 0xffffu;
-            const float r2 = r1 - __uint_as_float(b2 << 16);
-            const unsigned b3 = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+            // h split in three bf16 terms (WQ: two fp16 terms of h * 2^14); the odd unit of the pair sits 16 lanes up in
+            // this wave
+            unsigned b1, b2, b3;
+            if (WQ)
+            {
+                const float hs14 = h * HSCALE;
+                const _Float16 h1 = (_Float16)hs14, h2 = (_Float16)(hs14 - (float)h1);
+                b1 = __builtin_bit_cast(unsigned short, h1);
+                b2 = __builtin_bit_cast(unsigned short, h2);
+                b3 = 0u;
+            }
+            else
+            {
+                b1 = cvt_pk_bf16(h, 0.f) & 0xffffu;
+                const float r1 = h - __uint_as_float(b1 << 16);
+                b2 = cvt_pk_bf16(r1, 0.f) & 0xffffu;
+                const float r2 = r1 - __uint_as_float(b2 << 16);
+                b3 = cvt_pk_bf16(r2, 0.f) & 0xffffu;
+            }
             const unsigned mine12 = b1 | (b2 << 16);
             const unsigned other12 = (unsigned)__builtin_amdgcn_ds_swizzle((int)mine12, 0x401F); // lane ^ 16
-            const unsigned other3 = (unsigned)__builtin_amdgcn_ds_swizzle((int)b3, 0x401F);
+            const unsigned other3 = WQ ? 0u : (unsigned)__builtin_amdgcn_ds_swizzle((int)b3, 0x401F);
             if (lane_on)
             {
                 c = c_t;
