@@ -292,7 +292,8 @@ struct umx_hip_ctx
              unsigned create_flags, int n_tracks);
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
     bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
-    bool wiener_fused = true;     // wiener_istft.h (UMX_WIENER=unfused: the three-kernel path + separate inverse STFT)
+    bool wiener_fused = true;     // wiener_istft.h: gains + filter + inverse STFT frame in one kernel
+    bool wiener_stats4 = true;    // all-source statistics kernel (wiener_kernels.h)
     bool gemm_planes = false;     // ... with both operands pre-split / re-encoded as bf16 planes and LDS-DMA staging (gemm_planes.h)
     void launch_split(Lane &ln, int nl, hipStream_t st, int which, const int *active, int nact);
     void launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
@@ -499,8 +500,16 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     };
 
     gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // the bf16 matrix cores are the default
-    if (const char *e = getenv("UMX_WIENER")) // A/B switch: the unfused three-kernel Wiener path + separate inverse STFT
-        wiener_fused = std::string(e) != "unfused";
+    // Track-batched contexts fuse the Wiener filter with the inverse STFT (wiener_istft.h: one 1024-thread, 136 KB-LDS
+    // workgroup per frame); the single-track context keeps the small kernels, which run beside the other slot's LSTM
+    // grids (measured: fused 7.85 ms per segment in the pipeline, unfused 7.41).  UMX_WIENER = fused | stats4 | unfused.
+    wiener_fused = lstm_batched;
+    wiener_stats4 = true;
+    if (const char *e = getenv("UMX_WIENER"))
+    {
+        wiener_fused = std::string(e) == "fused";
+        wiener_stats4 = std::string(e) != "unfused";
+    }
     // gemm_planes.h for track-batched contexts (large tiles over all lanes); gemm_bf16x3.h for the single-track,
     // latency-optimised context, whose pipeline overlaps small GEMM blocks with two co-resident LSTM grids (the register
     // and LDS budget of DESIGN 4.2 was tuned for exactly that kernel).  Either can be forced.
@@ -1598,26 +1607,30 @@ int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const
         WienerMags wm;
         for (int s = 0; s < 4; ++s)
             wm.m[s] = L.ta[s].mag;
-        if (!wiener_fused)
+        const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+        if (flags & UMX_FLAG_NO_WIENER)
         {
-            if (flags & UMX_FLAG_NO_WIENER)
+            if (!wiener_fused)
             {
                 const size_t nel = (size_t)2 * T * NBINS;
                 hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, L.spec, wm, T, L.y);
+            }
+        }
+        else
+        {
+            if (wiener_stats4) // all four sources per thread, prefetched (same bits as the per-source kernel)
+            {
+                hipLaunchKernelGGL(wiener_stats4_kernel, dim3((NBINS + 63) / 64, nchunk), dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
+                hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, T, L.Rc, wiener_fused ? nullptr : L.R);
             }
             else
             {
                 hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.wpart,
                                    nbatch);
                 hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, nbatch, L.R);
-                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
             }
-        }
-        else if (!(flags & UMX_FLAG_NO_WIENER))
-        {
-            const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
-            hipLaunchKernelGGL(wiener_stats4_kernel, dim3((NBINS + 63) / 64, nchunk), dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
-            hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, T, L.Rc);
+            if (!wiener_fused)
+                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
         }
     }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));

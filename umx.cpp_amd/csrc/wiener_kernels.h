@@ -290,8 +290,9 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
     }
 }
 
-// grid (ceil(B/256), 4).  Rc: [4][2049][4] = {R00, Re R01, Im R01, R11}
-__global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__restrict__ part, int T, float *__restrict__ Rc)
+// grid (ceil(B/256), 4).  Rc: [4][2049][4] = {R00, Re R01, Im R01, R11}; R8 (optional): [4][2049][8]
+__global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__restrict__ part, int T, float *__restrict__ Rc,
+                                                             float *__restrict__ R8)
 {
     const int b = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
     if (b >= NBINS)
@@ -315,8 +316,14 @@ __global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__rest
             acc[i] += bs[i]; // wiener.cpp:243  R += batch sum
         weight += bs[4];     // wiener.cpp:247-253
     }
-    *reinterpret_cast<float4 *>(Rc + ((size_t)src * NBINS + b) * 4) =
-        make_float4(acc[0] / weight, acc[1] / weight, acc[2] / weight, acc[3] / weight); // wiener.cpp:259-269
+    const float4 r = make_float4(acc[0] / weight, acc[1] / weight, acc[2] / weight, acc[3] / weight); // wiener.cpp:259-269
+    *reinterpret_cast<float4 *>(Rc + ((size_t)src * NBINS + b) * 4) = r;
+    if (R8) // the eight-float form wiener_apply_kernel reads: R00, R01, R10 = conj(R01), R11
+    {
+        float4 *o = reinterpret_cast<float4 *>(R8 + ((size_t)src * NBINS + b) * 8);
+        o[0] = make_float4(r.x, 0.f, r.y, r.z);
+        o[1] = make_float4(r.y, -r.z, r.w, 0.f);
+    }
 }
 
 // The per-bin part of wiener_apply_kernel, split in two so that the fused kernel can hold many bins in registers:
