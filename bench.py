@@ -65,6 +65,9 @@ def algorithmic_work(T, H):
         "mixphase": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * 2 * T * NB * 2),
         "istft": 4.0 * (4 * 2 * T * NB * 2 + 4 * T * 4096 * 2),
         "ola": 4.0 * (4 * T * 4096 * 2 + 4 * 2 * T * 1024),
+        # round-2 fused forms: all-source statistics (mixture + 4 magnitudes read once); gains + filter + inverse STFT frame
+        "wiener_stats4": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB),
+        "wiener_istft": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * T * 4096 * 2),
     }
     return gemm, rec, byt
 
@@ -316,8 +319,10 @@ def main():
         planes = flavour in ("planes", "bf16x3")  # both run on the bf16 matrix cores
         gname = "gemm_planes_kernel" if flavour == "planes" else "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel"
         exact = planes and not args.expanded_weights and not args.u8_dequant  # integer weights as exact bf16 terms
-        p8 = 3 if exact else 6
-        p16 = 5 if (exact and flavour == "planes") else 6
+        # products per fp32 product: planes = 2 fp16 planes per activation x 1 (u8) or 2 (u16 / fp32) weight planes;
+        # bf16x3 = 3 bf16 terms per activation x 1 exact plane (u8) or the 6-product rule
+        p8 = (2 if exact else 4) if flavour == "planes" else (3 if exact else 6)
+        p16 = 4 if flavour == "planes" else 6
         # (the PMC summary holds demangled names: "void umx::gemm_planes_kernel<1, 1, 4, 4>(umx::GemmPArgs)" = <MODE, planes of B, WM, WN>)
         kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gname}<G_FC1>", (gname + "<0,",)),
                    gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gname}<G_IH>", (gname + "<1,",)),
@@ -328,8 +333,8 @@ def main():
         lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3
         lstm_alg = rec * B
         if batched:
-            lp = 3 if (not args.expanded_weights and not args.u8_dequant) else 6
-            lstm_issued = rec * 16 * lp * (1.25 if lp == 3 else 1.0)  # 16 tracks wide whatever B; + the all-ones tile of the u8 form
+            lp = 2 if (not args.expanded_weights and not args.u8_dequant) else 6  # u8 W_hh: 1 fp16 plane x 2 fp16 planes of h
+            lstm_issued = rec * 16 * lp * (1.25 if lp == 2 else 1.0)  # 16 tracks wide whatever B; + the all-ones tile of the u8 form
             lname = "lstm_batch_kernel"
         else:
             lstm_issued = lstm_alg
@@ -358,11 +363,17 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBS, 4),
                     "frac_alone": round(nbytes / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_alone > 0 else None,
                     "traffic": find_traffic(tneedle)}
-        kernels += [stream_entry("stft", "stft_kernel", byt["stft"], "stft_kernel"),
-                    stream_entry("wiener", "mixphase_kernel" if args.no_wiener else "wiener_{stats,finish,apply}_kernel (3 launches)",
-                                 byt["mixphase"] if args.no_wiener else byt["wiener"], "wiener_apply"),
-                    stream_entry("istft", "istft_frames_kernel", byt["istft"], "istft_frames"),
-                    stream_entry("ola", "istft_ola_kernel", byt["ola"], "istft_ola")]
+        wmode = os.environ.get("UMX_WIENER") or ("fused" if batched else "stats4")
+        kernels.append(stream_entry("stft", "stft_kernel", byt["stft"], "stft_kernel"))
+        if wmode == "fused":  # track-batched default: statistics, then gains + filter + inverse STFT frame in one kernel
+            if not args.no_wiener:
+                kernels.append(stream_entry("wiener", "wiener_stats4_kernel (+ finish4)", byt["wiener_stats4"], "wiener_stats4"))
+            kernels.append(stream_entry("istft", "wiener_istft_kernel", byt["wiener_istft"], "wiener_istft"))
+        else:
+            kernels += [stream_entry("wiener", "mixphase_kernel" if args.no_wiener else "wiener_{stats,finish,apply}_kernel (3 launches)",
+                                     byt["mixphase"] if args.no_wiener else byt["wiener"], "wiener_apply"),
+                        stream_entry("istft", "istft_frames_kernel", byt["istft"], "istft_frames")]
+        kernels.append(stream_entry("ola", "istft_ola_kernel", byt["ola"], "istft_ola"))
         dominant = max(kernels, key=lambda kk: kk["launch_ms"] * kk["launches_per_step"])
         roofline = {kk: dominant.get(kk) for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
                                                     "launch_ms_alone", "launches_per_step", "algorithmic_flops_per_launch",
@@ -395,9 +406,9 @@ def main():
                        "audio_seconds_per_step": B * seg_sec,
                        "lstm_kernel": ("batched, matrix cores (lstm_batch_kernel)" if batched else "single-track, VALU (lstm_persistent_kernel)"),
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
-                       "gemm": (flavour + (" (bf16 matrix cores, f32 accumulate: activations split once into 3 bf16 planes, u8 weights exact in "
-                                           "1 plane (3 products), u16 weights exact in 2 planes (5 products), LDS-DMA staging, 256x256 tiles "
-                                           "over all track lanes)" if flavour == "planes" else
+                       "gemm": (flavour + (" (fp16 matrix cores, f32 accumulate: activations split once into 2 fp16 planes of the power-of-two "
+                                           "scaled row, u8 weights exact in 1 plane (2 products), u16 weights exact in 2 planes (4 products), "
+                                           "LDS-DMA staging, 256x256 tiles over all track lanes)" if flavour == "planes" else
                                            " (fp32 operands split into 3 bf16 terms while staged, 3 / 6 products)" if flavour == "bf16x3"
                                            else " MFMA")),
                        "weights_resident": ("expanded at load (f32 / bf16 planes)" if args.expanded_weights
