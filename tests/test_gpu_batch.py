@@ -75,6 +75,41 @@ def test_track_bits_do_not_depend_on_lane_companions_or_batch_size(pkg, tmp_path
                 assert (outs[s][t] == ref_outs[s][t]).all(), (B, lane, flags, s, t)
 
 
+def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path):
+    """Lanes follow each other every T rows in the lane-contiguous activation buffers, so the 128- / 256-row tiles of the
+    plane GEMMs hold rows of two lanes whenever T is not a multiple of the tile (the production T = 2584 is not): 301
+    frames, three lanes of different audio, one of them absent in the second call.  Per lane: the oracle's answer, the
+    mask tap included (the fc3 epilogue maps rows to (lane, frame) itself), and the bits of the same track alone."""
+    hidden, N, B, NSEG = 128, 300 * 1024, 3, 2
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(hidden, seed=53), hidden, compress=False)
+    om = po.Model.load(path)
+    waves = [[pkg.ggml.synth_audio(N - 1000 * b, 800 + 10 * b + s) for s in range(NSEG)] for b in range(B)]
+    eng = pkg.Engine.from_file(path, N, tracks=B)
+    assert eng.T == 301
+    got, masks = [], []
+    for s in range(NSEG):
+        batch = [waves[b][s] for b in range(B)]
+        if s == 1:
+            batch[1] = None  # lane 1 sits the second call out
+        got.append(eng.infer_batch(batch, pkg.FLAG_DEBUG_TAPS))
+        masks.append([None if batch[b] is None else eng.tap(f"mask#{b}", 2) for b in range(B)])
+    eng.close()
+    for b in range(B):
+        st = po.stream_state(hidden)
+        alone = pkg.Engine.from_file(path, N, tracks=1, lstm_batched=True, gemm="planes")
+        for s in range(NSEG):
+            if s == 1 and b == 1:
+                continue
+            ref, taps = po.umx_inference(om, waves[b][s], n_buf=N, state=st, want_taps=True)
+            one = alone.infer_batch([waves[b][s]])[0]
+            for t in range(4):
+                assert float(np.abs(got[s][b][t] - ref[t]).max()) < TOL_WAVE, (b, s, t)
+                assert (got[s][b][t] == one[t]).all(), (b, s, t)
+            assert rel_l2(masks[s][b], taps["mask"][2]) < TOL_STAGE, (b, s)
+        alone.close()
+
+
 def test_batched_kernel_agrees_with_single_track_kernel(pkg, tmp_path):
     """Same track through the single-track (VALU) kernel and the batched (matrix-core) kernel: different summation
     order, so not bitwise -- but far inside the parity tolerance."""

@@ -218,6 +218,7 @@ static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
 struct umx_hip_ctx
 {
     int device = 0, H = 0, Hl = 0, S = 0, N = 0, T = 0, Tp = 0, nbatch = 0;
+    static constexpr int Mpad = 256; // slack rows behind the last lane: a launch's M is rounded up to the 256-row tile
     std::string err;
     std::vector<void *> allocs;
     TargetBufs tb[4];
@@ -420,7 +421,11 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     S = Hl / LSTM_UNITS_PER_WG;
     N = segment_samples;
     T = N / HOP + 1; // dsp.hpp:48
-    Tp = round_up(T, 256); // multiple of the largest GEMM M tile: a tile never straddles two track lanes
+    // rows per track lane of the lane-contiguous activation buffers.  Plane GEMMs run over all lanes at once and their
+    // tiles may straddle lanes, so lanes follow each other without padding (T rows; 8 % fewer tile rows than lanes padded
+    // to the 256-row tile) and only the END of a launch is padded to a tile (Mpad rows of slack in every buffer);
+    // the per-lane GEMM flavours launch M = Tp per lane and need whole 128-row tiles.
+    Tp = T; // provisional: fixed below once the GEMM flavour is known
     nbatch = (T + WIENER_BATCH - 1) / WIENER_BATCH;
 
     // ---- index the tensor views by (target, name)
@@ -515,6 +520,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     // and LDS budget of DESIGN 4.2 was tuned for exactly that kernel).  Either can be forced.
     gemm_planes = gemm_bf16x3 && ((create_flags & UMX_CREATE_GEMM_PLANES) || (lstm_batched && !(create_flags & UMX_CREATE_GEMM_STAGED)));
     const bool bx = gemm_bf16x3;
+    Tp = gemm_planes ? std::max(T, 256) : round_up(T, 128); // (a tile must not hold rows of more than two lanes)
     // A GEMM weight as fp16 planes (PMat): (rows x cols) of `tv` (u8 / u16 as stored: exact integers) or of `f32` (two
     // split terms of w * 2^e, 2^e bringing the tensor's largest |w| into [2^14, 2^15); returns 2^-e), source row
     // rowmap[r] -> destination row dst_row0 + r of a [nbp][total_rows][cols_pad] matrix built in `host`
@@ -926,22 +932,22 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         // Buffers that a launch covering several track lanes reads or writes (the batched LSTM kernel, the plane GEMMs
         // with M = lanes x Tp) are ONE allocation per slot (and target), lane after lane at a constant stride.
         float *x_all = nullptr, *mixmag_all = nullptr;
-        if (int rc = dalloc(&x_all, (size_t)B * Tp * KX))
+        if (int rc = dalloc(&x_all, ((size_t)B * Tp + Mpad) * KX))
             return rc;
         if (int rc = dalloc(&mixmag_all, (size_t)B * 2 * T * NBINS))
             return rc;
         for (int tg = 0; tg < 4; ++tg)
         {
             float *cat_all = nullptr, *la_all = nullptr, *lb_all = nullptr, *P_all = nullptr, *a2_all = nullptr, *mag_all = nullptr;
-            if (int rc = dalloc(&cat_all, (size_t)B * Tp * 2 * H))
+            if (int rc = dalloc(&cat_all, ((size_t)B * Tp + Mpad) * 2 * H))
                 return rc;
-            if (int rc = dalloc(&la_all, (size_t)B * Tp * H))
+            if (int rc = dalloc(&la_all, ((size_t)B * Tp + Mpad) * H))
                 return rc;
-            if (int rc = dalloc(&lb_all, (size_t)B * Tp * H))
+            if (int rc = dalloc(&lb_all, ((size_t)B * Tp + Mpad) * H))
                 return rc;
-            if (int rc = dalloc(&P_all, (size_t)B * Tp * 4 * H))
+            if (int rc = dalloc(&P_all, ((size_t)B * Tp + Mpad) * 4 * H))
                 return rc;
-            if (int rc = dalloc(&a2_all, (size_t)B * Tp * H))
+            if (int rc = dalloc(&a2_all, ((size_t)B * Tp + Mpad) * H))
                 return rc;
             if (int rc = dalloc(&mag_all, (size_t)B * 2 * T * NBINS))
                 return rc;
@@ -949,15 +955,15 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             float *rs[8] = {};
             if (gemm_planes) // planes [2][B * Tp][K]: plane-major over ALL lanes, so that M runs across the lanes
             {
-                if (int rc = dalloc(&xs_p, (size_t)2 * B * Tp * KX))
+                if (int rc = dalloc(&xs_p, 2 * ((size_t)B * Tp + Mpad) * KX))
                     return rc;
-                if (int rc = dalloc(&cat_p, (size_t)2 * B * Tp * 2 * H))
+                if (int rc = dalloc(&cat_p, 2 * ((size_t)B * Tp + Mpad) * 2 * H))
                     return rc;
                 for (unsigned short **q : {&la_p, &lb_p, &a2_p})
-                    if (int rc = dalloc(q, (size_t)2 * B * Tp * H))
+                    if (int rc = dalloc(q, 2 * ((size_t)B * Tp + Mpad) * H))
                         return rc;
                 for (int k = 0; k < 8; ++k)
-                    if (int rc = dalloc(&rs[k], (size_t)B * Tp))
+                    if (int rc = dalloc(&rs[k], (size_t)B * Tp + Mpad))
                         return rc;
             }
             for (int ln = 0; ln < B; ++ln)
@@ -1422,7 +1428,7 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
     memset(&a, 0, sizeof a);
     a.T = T;
     a.Tp = Tp;
-    const size_t rows_all = (size_t)B * Tp; // rows of one output plane
+    const size_t rows_all = (size_t)B * Tp + Mpad; // rows of one output plane
     for (int i = 0; i < nact; ++i)
     {
         const TargetBufs &b = tb[active[i]];
@@ -1455,20 +1461,22 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
             break;
         }
     }
-    hipLaunchKernelGGL(split_planes_kernel, dim3(nl * Tp, 1, nact), dim3(256), 0, st, a);
+    a.rows_valid = nl * Tp;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(round_up(nl * Tp, 256), 1, nact), dim3(256), 0, st, a);
 }
 
 void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg)
 {
     GemmPArgs g;
     memset(&g, 0, sizeof g);
-    g.M = nl * Tp;
+    g.M = round_up(nl * Tp, 256); // rows behind the last lane of the launch are zero planes (split_planes_kernel)
+    g.lanes = nl;
     g.T = T;
     g.Tp_lane = Tp;
     g.mag_lane = (size_t)2 * T * NBINS;
     g.dbg_lane = (size_t)T * NOUT;
     g.a_unscale = 1.0f / (float)(1 << GP_SPLIT_FIXED_EXP); // tanh / LSTM outputs: constant scale (split_planes_kernel)
-    const size_t rows_all = (size_t)B * Tp;
+    const size_t rows_all = (size_t)B * Tp + Mpad;
     int nbp = 2;
     for (int i = 0; i < nact; ++i)
     {

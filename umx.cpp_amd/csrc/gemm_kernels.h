@@ -56,7 +56,7 @@ struct GemmArgs
     int M, N, K, lda, ldc, T;
     // several track lanes in one launch (gemm_planes.h): M = lanes x Tp_lane rows; the FC3 epilogue's per-lane buffers
     // (mix magnitude in, target magnitude out, mask tap) then sit mag_lane / dbg_lane floats apart.  0 = one lane.
-    int Tp_lane;
+    int Tp_lane, lanes; // lanes: track lanes of the launch (0: M / Tp_lane)
     size_t mag_lane, dbg_lane;
 };
 
@@ -112,8 +112,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
                                               int lr, int lh, const floatx16 &acc00, const floatx16 &acc01,
                                               const floatx16 &acc10, const floatx16 &acc11)
 {
-    int f0 = m0;          // frame of row m0 inside its track lane
+    // fc3: rows -> (track lane, frame).  Lanes follow each other every Tp_lane rows (>= the tile height), so a block
+    // holds rows of at most two lanes: the lane of its first row is a scalar, a row past `m_next` belongs to the next one.
+    int f0 = m0;             // frame of row m0 inside its track lane
     unsigned lo = 0, ld = 0; // element offsets of that lane in the magnitude / debug outputs
+    const int tpl = args.Tp_lane ? args.Tp_lane : (1 << 30); // rows per lane (one lane: never reached)
     if (MODE == G_FC3 && args.Tp_lane)
     {
         const int ln = __builtin_amdgcn_readfirstlane(m0 / args.Tp_lane);
@@ -121,13 +124,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
         lo = (unsigned)(ln * args.mag_lane);
         ld = (unsigned)(ln * args.dbg_lane);
     }
+    const int m_next = tpl - f0; // first row of the block's second lane, relative to m0
+    // per lane, once: its first row of the block, that row's frame in either lane, and both as byte offsets
+    const int mlb = wm * 64 + 4 * lh;                 // rows of this lane: mlb + (mi*32 + 8 rq + j)
+    const int fA = f0 + mlb, fB = mlb - m_next;       // frame of row mlb if it is in the block's first / second lane
+    const unsigned dA = ((unsigned)args.mag_lane - (unsigned)args.Tp_lane * NBINS) * 4u; // second lane: + lane stride, - Tp rows
+    const unsigned dD = ((unsigned)args.dbg_lane - (unsigned)args.Tp_lane * NOUT) * 4u;
+    const bool has_dbg = MODE == G_FC3 && tg.dbg != nullptr;
     // fc3 only (dead code elsewhere): buffer resources of the magnitude output, the mix magnitude and the debug tap
-    const int lanes = args.Tp_lane ? args.M / args.Tp_lane : 1;
+    const int lanes = args.Tp_lane ? (args.lanes ? args.lanes : args.M / args.Tp_lane) : 1;
     const int mag_bytes = MODE == G_FC3 ? (int)((args.Tp_lane ? (size_t)lanes * args.mag_lane : (size_t)2 * args.T * NBINS) * 4) : 0;
     const int dbg_bytes = MODE == G_FC3 && tg.dbg ? (int)((args.Tp_lane ? (size_t)lanes * args.dbg_lane : (size_t)args.T * NOUT) * 4) : 0;
     const __amdgpu_buffer_rsrc_t rs_mag = __builtin_amdgcn_make_buffer_rsrc(tg.C, 0, mag_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == G_FC3 ? tg.aux : tg.C), 0, mag_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dbg = __builtin_amdgcn_make_buffer_rsrc(MODE == G_FC3 && tg.dbg ? tg.dbg : tg.C, 0, dbg_bytes, 0x00020000);
+    // fc3's debug tap of the mask is a separate (cold) pass over the accumulators, so that the hot pass carries neither
+    // its offsets nor a branch per group of rows
+    auto pass = [&](auto dbg_tag) {
+    constexpr bool DBG = decltype(dbg_tag)::value;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
     {
@@ -151,6 +165,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
             const int c = n >= NBINS ? 1 : 0;
             col = lo + (unsigned)(c * args.T) * NBINS + (unsigned)(n - c * NBINS);
         }
+        // running values of the row loop below (incremented row by row: a handful of constants instead of one literal per
+        // row, which the compiler would all keep in SGPRs): byte offsets of (row, column n) in the block's FIRST lane, and
+        // the row's frame index relative to the block's SECOND lane (negative while the row is still in the first)
+        unsigned run = (col + (unsigned)fA * NBINS) * 4u, drun = (ld + (unsigned)fA * NOUT + (unsigned)n) * 4u;
+        int frow = fB;
         // fc3: frames >= T (M padding) and columns >= NOUT (N padding) are dropped by the buffer range check (their
         // byte offset is replaced by one past the end), and so is the whole debug tap when there is none (a resource of
         // zero records): no branch and no 64-bit address arithmetic per element
@@ -160,6 +179,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
             {
+                float ys[4];
+                unsigned offs[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                 {
@@ -177,20 +198,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
                             tg.C[(size_t)(m0 + ml) * args.ldc + n] = fmaxf(y, 0.f);
                         else
                         {
-                            const int f = f0 + ml;
+                            const bool second = frow >= 0; // the row belongs to the next track lane
+                            const int f = second ? frow : frow + tpl;
                             const bool ok = col_ok && f < args.T;
-                            y = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
-                            const unsigned off = ok ? (col + (unsigned)f * NBINS) * 4u : 0xfffffff0u;
-                            const unsigned offd = ok ? (ld + (unsigned)f * NOUT + (unsigned)n) * 4u : 0xfffffff0u;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_dbg, offd, 0, 0);
-                            const float mix = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_aux, off, 0, 0));
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y * mix), rs_mag, off, 0, 0); // inference.cpp:175-183
+                            ys[j] = fmaxf(y * osc + omn, 0.f); // inference.cpp:161-166
+                            // (a lane past the launch's last one lands beyond the resources' range and is dropped)
+                            offs[j] = ok ? (DBG ? drun + (second ? dD : 0u) : run + (second ? dA : 0u)) : 0xfffffff0u;
+                            run += NBINS * 4;
+                            drun += NOUT * 4;
+                            frow += 1;
                         }
                     }
                 }
+                if (MODE == G_FC3 && DBG)
+                {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ys[j]), rs_dbg, offs[j], 0, 0);
+                    run += 4 * NBINS * 4;
+                    drun += 4 * NOUT * 4;
+                    frow += 4;
+                }
+                else if (MODE == G_FC3)
+                {
+                    float mix[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        mix[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_aux, offs[j], 0, 0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ys[j] * mix[j]), rs_mag, offs[j], 0, 0); // inference.cpp:175-183
+                    run += 4 * NBINS * 4; // the next group of four rows starts eight rows further
+                    drun += 4 * NOUT * 4;
+                    frow += 4;
+                }
                 asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0); // ... and the arithmetic of the next group of rows behind this group's
             }
     }
+    };
+    if (MODE == G_FC3 && has_dbg)
+        pass(std::true_type{});
+    pass(std::false_type{});
 }
 
 enum GemmBType

@@ -56,6 +56,7 @@ struct GemmPArgs
     size_t a_plane; // elements between A planes
     float a_unscale; // inverse of the constant scale of A when t[].rsc == nullptr
     int Tp_lane;    // rows per track lane when M spans several lanes (0: one lane); FC3 epilogue, see GemmArgs
+    int lanes;      // track lanes of the launch (M >= lanes * Tp_lane, rounded up to the tile)
     size_t mag_lane, dbg_lane;
 };
 
@@ -120,6 +121,7 @@ struct SplitArgs
     float *rowunscale[4];            // per-row inverse scale out (adaptive scaling); nullptr: the constant 2^GP_SPLIT_FIXED_EXP
     const float *scale[4], *mean[4]; // fc1 prologue x*scale+mean (inference.cpp:78-83, F8 order); nullptr otherwise
     int T, Tp, cols, ld_src, ld_dst, col0_dst; // row m of the grid = frame m % Tp of track lane m / Tp; frames >= T are padding
+    int rows_valid;                  // rows >= rows_valid (behind the last lane of the launch) are padding too
     size_t plane;                    // elements between output planes
 };
 
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs a)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             xs[it][j] = 0.f;
-        if (k < a.cols && m % a.Tp < a.T) // rows of the M padding are zero planes
+        if (k < a.cols && m < a.rows_valid && m % a.Tp < a.T) // rows of the M padding are zero planes
         {
             const float4 v0 = *reinterpret_cast<const float4 *>(src + k), v1 = *reinterpret_cast<const float4 *>(src + k + 4);
             xs[it][0] = v0.x; xs[it][1] = v0.y; xs[it][2] = v0.z; xs[it][3] = v0.w;
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
     ea.ldc = args.ldc;
     ea.T = args.T;
     ea.Tp_lane = args.Tp_lane;
+    ea.lanes = args.lanes;
     ea.mag_lane = args.mag_lane;
     ea.dbg_lane = args.dbg_lane;
     gemm_epilogue<MODE>(et, ea, m0, n0, wm, wn, lr, lh, acc00, acc01, acc10, acc11);
