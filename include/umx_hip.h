@@ -271,6 +271,9 @@ int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48);
  * for them and returns {words found changed, events} in out2.  Used to show that no kernel of this engine writes
  * into another workgroup's LDS. */
 int umx_hip_debug_lds_guard(umx_hip_ctx *ctx, int launches, int rounds, unsigned *out2);
+/* Testing hook (no GPU needed): the host-side fp32 -> fp16 conversion (round to nearest even, subnormals, overflow to
+ * infinity) with which weights are re-encoded as fp16 planes at load time (csrc/gemm_planes.h); returns the 16 bits. */
+unsigned umx_hip_debug_f16_bits(float x);
 
 #ifdef __cplusplus
 }

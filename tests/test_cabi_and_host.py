@@ -25,6 +25,24 @@ def test_hip_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.HIP_SYMBOLS) == names
 
 
+def test_host_side_fp16_encoding_of_weight_planes_is_round_to_nearest_even(pkg):
+    """csrc/gemm_planes.h re-encodes weights as fp16 planes on the host at load time (u8 / u16 integers exactly, fp32
+    weights as two split terms): its fp32 -> fp16 conversion against numpy's, over random values of every magnitude
+    class (normal, subnormal, underflow, overflow, ties) and every integer a weight plane can hold."""
+    lib = pkg.hip_lib()
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([
+        rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-9, 6, 20000).astype(np.float32),
+        np.arange(-32768, 32768, 7, dtype=np.float32), np.arange(-128, 128, dtype=np.float32) * 256.0,
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25, 2.0 ** -14,
+                  2.0 ** -14 - 2.0 ** -25, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 2049.0, 2051.0, np.inf, -np.inf], dtype=np.float32)])
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    got = np.array([lib.umx_hip_debug_f16_bits(float(v)) for v in vals], dtype=np.uint16)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, [(float(vals[i]), hex(int(got[i])), hex(int(want[i]))) for i in bad[:5]]
+
+
 def test_host_library_exports_every_declared_symbol(pkg):
     lib = ctypes.CDLL(str(ROOT / "umx.cpp_amd" / "libumx_host.so"))
     names = _declared("umx_host.h")

@@ -81,6 +81,8 @@ def hip_lib():
                                           C.c_uint, C.c_int]
     lib.umx_hip_n_tracks.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_is_batched.argtypes = [C.c_void_p]
+    lib.umx_hip_debug_f16_bits.argtypes = [C.c_float]
+    lib.umx_hip_debug_f16_bits.restype = C.c_uint
     lib.umx_hip_track_stream_reset.argtypes = [C.c_void_p, C.c_int]
     lib.umx_hip_track_stream_get.argtypes = [C.c_void_p, C.c_int, _fp]
     lib.umx_hip_track_stream_set.argtypes = [C.c_void_p, C.c_int, _fp]
@@ -154,7 +156,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
-               "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard"]
+               "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits"]
 
 
 def views_from_file_tensors(targets, quantised=True):

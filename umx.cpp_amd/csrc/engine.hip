@@ -1092,8 +1092,13 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC3, BQ_U16>)};
         for (const void *fn : bxs)
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
-        UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, WI_LDS_BYTES));
-        UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, WI_LDS_BYTES));
+        {
+            const int wi_lds = 4 * FFT_LDS_ELEMS * (int)sizeof(float2); // 139,264 (NSRC = 4; 2 and 1 need less)
+            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
+            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
+            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds / 2));
+            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds / 2));
+        }
 #define UMX_GP_ATTR(MODE)                                                                                              \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 2))); \
@@ -1628,7 +1633,14 @@ int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const
         {
             if (wiener_stats4) // all four sources per thread, prefetched (same bits as the per-source kernel)
             {
-                hipLaunchKernelGGL(wiener_stats4_kernel, dim3((NBINS + 63) / 64, nchunk), dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
+                static const int ns = getenv("UMX_WIENER_NS") ? atoi(getenv("UMX_WIENER_NS")) : 2; // sources per thread (measured: 4: 0.151, 2: 0.128, 1: 0.131 ms per track)
+                const dim3 g((NBINS + 63) / 64, nchunk, 4 / (ns == 1 || ns == 2 ? ns : 4));
+                if (ns == 1)
+                    hipLaunchKernelGGL(wiener_stats4_kernel<1>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
+                else if (ns == 2)
+                    hipLaunchKernelGGL(wiener_stats4_kernel<2>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
+                else
+                    hipLaunchKernelGGL(wiener_stats4_kernel<4>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
                 hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, T, L.Rc, wiener_fused ? nullptr : L.R);
             }
             else
@@ -1655,12 +1667,15 @@ int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const
                 for (int s = 0; s < 4; ++s)
                     wm.m[s] = L.ta[s].mag;
                 float2 *ydbg = dbg ? L.y : nullptr;
-                if (flags & UMX_FLAG_NO_WIENER)
-                    hipLaunchKernelGGL((wiener_istft_kernel<false>), dim3(T), dim3(WI_THREADS), WI_LDS_BYTES, st, L.spec, wm, T, L.maxabs, L.Rc, window, nw,
-                                       tw1, tw2, L.frames, ydbg);
-                else
-                    hipLaunchKernelGGL((wiener_istft_kernel<true>), dim3(T), dim3(WI_THREADS), WI_LDS_BYTES, st, L.spec, wm, T, L.maxabs, L.Rc, window, nw,
-                                       tw1, tw2, L.frames, ydbg);
+                static const int nsrc = getenv("UMX_WIENER_NSRC") ? atoi(getenv("UMX_WIENER_NSRC")) : 4; // sources per workgroup (tuning knob)
+#define UMX_WI(W, NS)                                                                                                \
+    hipLaunchKernelGGL((wiener_istft_kernel<W, NS>), dim3(T, 4 / NS), dim3(256 * NS), (size_t)NS * FFT_LDS_ELEMS * sizeof(float2), st, \
+                       L.spec, wm, T, L.maxabs, L.Rc, window, nw, tw1, tw2, L.frames, ydbg)
+                const bool nowi = flags & UMX_FLAG_NO_WIENER;
+                if (nsrc == 1) { if (nowi) UMX_WI(false, 1); else UMX_WI(true, 1); }
+                else if (nsrc == 2) { if (nowi) UMX_WI(false, 2); else UMX_WI(true, 2); }
+                else { if (nowi) UMX_WI(false, 4); else UMX_WI(true, 4); }
+#undef UMX_WI
             }
         }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
@@ -2272,6 +2287,8 @@ int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int se
 
 int umx_hip_n_tracks(const umx_hip_ctx *ctx) { return ctx ? ctx->B : 0; }
 int umx_hip_lstm_is_batched(const umx_hip_ctx *ctx) { return ctx && ctx->lstm_batched ? 1 : 0; }
+
+unsigned umx_hip_debug_f16_bits(float x) { return f16_rne_bits(x); }
 
 void umx_hip_destroy(umx_hip_ctx *ctx)
 {

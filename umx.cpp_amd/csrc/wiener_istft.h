@@ -24,22 +24,31 @@
 namespace umx
 {
 
-constexpr int WI_THREADS = 1024;
-constexpr int WI_LDS_BYTES = 4 * FFT_LDS_ELEMS * (int)sizeof(float2); // 139,264
+// NSRC = sources per workgroup (4: one workgroup per frame as described above; 2 / 1: grid.y = 2 / 4 workgroups per frame,
+// each repeating phase 1's source-independent part for its own bins -- the second reads hit the L2 -- in exchange for
+// 2 / 4 workgroups per CU whose phases overlap)
+// rc[s] for a run-time s without indexing the array (it stays in registers)
+__device__ __forceinline__ float4 sel4(int s, const float4 (&r)[4])
+{
+    return make_float4(s == 0 ? r[0].x : s == 1 ? r[1].x : s == 2 ? r[2].x : r[3].x, s == 0 ? r[0].y : s == 1 ? r[1].y : s == 2 ? r[2].y : r[3].y,
+                       s == 0 ? r[0].z : s == 1 ? r[1].z : s == 2 ? r[2].z : r[3].z, s == 0 ? r[0].w : s == 1 ? r[1].w : s == 2 ? r[2].w : r[3].w);
+}
 
-template <bool WIENER>
-__global__ __launch_bounds__(WI_THREADS) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
+template <bool WIENER, int NSRC>
+__global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
                                                                   const unsigned *__restrict__ maxabs_bits,
                                                                   const float *__restrict__ Rc, const float *__restrict__ window,
                                                                   const float *__restrict__ nw, const float2 *__restrict__ tw1,
                                                                   const float2 *__restrict__ tw2, float2 *__restrict__ frames,
                                                                   float2 *__restrict__ y_dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [4][FFT_LDS_ELEMS]
+    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [NSRC][FFT_LDS_ELEMS]
+    constexpr int WI_THREADS = 256 * NSRC;
+    const int src0 = NSRC * blockIdx.y;
     const int f = blockIdx.x, tid = threadIdx.x;
     const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < (NFFT / 2 + WI_THREADS) / WI_THREADS; ++q)
     {
         const int b = tid + WI_THREADS * q;
         if (b > NFFT / 2)
@@ -69,15 +78,18 @@ __global__ __launch_bounds__(WI_THREADS) void wiener_istft_kernel(const float2 *
             p1 = unit_phasor(X1);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int sl = 0; sl < NSRC; ++sl)
         {
+            const int s = src0 + sl;
             float2 o[2];
             if (WIENER)
-                wiener_bin_apply(wb, s, rc[s], max_abs, o);
+                wiener_bin_apply(wb, s, NSRC == 4 ? rc[sl] : sel4(s, rc), max_abs, o);
             else
             {
-                o[0] = make_float2(m0[s] * p0.x, m0[s] * p0.y);
-                o[1] = make_float2(m1[s] * p1.x, m1[s] * p1.y);
+                const float ms0 = NSRC == 4 ? m0[sl] : (s == 0 ? m0[0] : s == 1 ? m0[1] : s == 2 ? m0[2] : m0[3]);
+                const float ms1 = NSRC == 4 ? m1[sl] : (s == 0 ? m1[0] : s == 1 ? m1[1] : s == 2 ? m1[2] : m1[3]);
+                o[0] = make_float2(ms0 * p0.x, ms0 * p0.y);
+                o[1] = make_float2(ms1 * p1.x, ms1 * p1.y);
             }
             if (y_dbg)
             {
@@ -90,14 +102,14 @@ __global__ __launch_bounds__(WI_THREADS) void wiener_istft_kernel(const float2 *
                 a.y = 0.f;
                 bb.y = 0.f;
             }
-            float2 *buf = wi_buf + s * FFT_LDS_ELEMS;
+            float2 *buf = wi_buf + sl * FFT_LDS_ELEMS;
             buf[fft_pad(b)] = make_float2(a.x - bb.y, a.y + bb.x); // a + i b
             if (b > 0 && b < NFFT / 2)
                 buf[fft_pad(NFFT - b)] = make_float2(a.x + bb.y, bb.x - a.y); // conj(a) + i conj(b)
         }
     }
     __syncthreads();
-    const int g = tid >> 8, j = tid & 255; // source, thread of its transform
+    const int g = tid >> 8, j = tid & 255; // source (of this workgroup's), thread of its transform
     float2 *buf = wi_buf + g * FFT_LDS_ELEMS;
     float2 v[16];
 #pragma unroll
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(WI_THREADS) void wiener_istft_kernel(const float2 *
         v[r] = buf[fft_pad(j + 256 * r)];
     __syncthreads();
     fft4096<true>(v, buf, tw1, tw2, j);
-    float2 *dst = frames + ((size_t)g * T + f) * NFFT;
+    float2 *dst = frames + ((size_t)(src0 + g) * T + f) * NFFT;
     const size_t start = (size_t)f * HOP;
 #pragma unroll
     for (int r = 0; r < 16; ++r)

@@ -208,39 +208,51 @@ constexpr int WIENER_CHUNK = WIENER_BATCH; // frames per thread of wiener_stats4
 static_assert(WIENER_BATCH % WIENER_CHUNK == 0, "chunks must not straddle the reference's batches");
 constexpr int WIENER_PF = 8;               // frames per prefetch group
 
-struct WienerFrame // what one frame contributes to one bin: mixture (2 channels) and 4 x 2 magnitudes
+template <int NS> struct WienerFrame // what one frame contributes to one bin: mixture (2 channels) and NS x 2 magnitudes
 {
     float2 X0, X1;
-    float m0[4], m1[4];
+    float m0[NS], m1[NS];
 };
-__device__ __forceinline__ void wiener_frame_load(WienerFrame &w, const float2 *__restrict__ spec, const WienerMags &mags, int T,
-                                                  int f, int b)
+template <int NS>
+__device__ __forceinline__ void wiener_frame_load(WienerFrame<NS> &w, const float2 *__restrict__ spec, const float *const (&mag)[NS],
+                                                  int T, int f, int b)
 {
     const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
     w.X0 = spec[i0];
     w.X1 = spec[i1];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < NS; ++s)
     {
-        w.m0[s] = mags.m[s][i0];
-        w.m1[s] = mags.m[s][i1];
+        w.m0[s] = mag[s][i0];
+        w.m1[s] = mag[s][i1];
     }
 }
 
-// grid (ceil(B/64), nchunk), 64 threads.  part: [nchunk][4 sources][5][2049] = R00, Re R01, Im R01, R11, sum v (bin fastest)
+// grid (ceil(B/64), nchunk, 4 / NS), 64 threads; a thread handles the NS sources NS z .. NS z + NS - 1 (the more sources
+// per thread, the fewer times the mixture is read and its phasor formed; the fewer, the more waves to spread over the
+// chip: the accumulation is arithmetic- and latency-bound per wave).
+// part: [nchunk][4 sources][5][2049] = R00, Re R01, Im R01, R11, sum v (bin fastest)
+template <int NS>
 __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
                                                            const unsigned *__restrict__ maxabs_bits,
                                                            float *__restrict__ part)
 {
     const int b = min(blockIdx.x * 64 + threadIdx.x, NBINS - 1), chunk = blockIdx.y; // surplus lanes repeat the last bin
+    const int s0 = NS * blockIdx.z;
     const float max_abs = wiener_max_abs(maxabs_bits), rmax = 1.0f / max_abs;
     const int f0 = chunk * WIENER_CHUNK, f1 = min(T, f0 + WIENER_CHUNK);
-    float r00[4] = {0.f, 0.f, 0.f, 0.f}, r01x[4] = {0.f, 0.f, 0.f, 0.f}, r01y[4] = {0.f, 0.f, 0.f, 0.f},
-          r11[4] = {0.f, 0.f, 0.f, 0.f}, wsum[4] = {0.f, 0.f, 0.f, 0.f};
-    auto accumulate = [&](const WienerFrame &w) {
+    const float *mag[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        mag[s] = NS == 4 ? mags.m[s] : (s0 + s == 0 ? mags.m[0] : s0 + s == 1 ? mags.m[1] : s0 + s == 2 ? mags.m[2] : mags.m[3]);
+    float r00[NS], r01x[NS], r01y[NS], r11[NS], wsum[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        r00[s] = r01x[s] = r01y[s] = r11[s] = wsum[s] = 0.f;
+    auto accumulate = [&](const WienerFrame<NS> &w) {
         const float2 p0 = unit_phasor(w.X0), p1 = unit_phasor(w.X1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < NS; ++s)
         {
             // wiener_y0 with the division by max_abs as an exact 3-instruction quotient (div_by, common.h)
             const float2 y0 = make_float2(div_by(w.m0[s] * p0.x, max_abs, rmax), div_by(w.m0[s] * p0.y, max_abs, rmax));
@@ -259,15 +271,15 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
             r11[s] += (0.f + q11.x);
         }
     };
-    WienerFrame cur[WIENER_PF], nxt[WIENER_PF];
+    WienerFrame<NS> cur[WIENER_PF], nxt[WIENER_PF];
 #pragma unroll
     for (int k = 0; k < WIENER_PF; ++k)
-        wiener_frame_load(cur[k], spec, mags, T, min(f0 + k, f1 - 1), b);
+        wiener_frame_load<NS>(cur[k], spec, mag, T, min(f0 + k, f1 - 1), b);
     for (int f = f0; f < f1; f += WIENER_PF)
     {
 #pragma unroll
         for (int k = 0; k < WIENER_PF; ++k) // the next group is in flight while this one is accumulated
-            wiener_frame_load(nxt[k], spec, mags, T, min(f + WIENER_PF + k, f1 - 1), b);
+            wiener_frame_load<NS>(nxt[k], spec, mag, T, min(f + WIENER_PF + k, f1 - 1), b);
 #pragma unroll
         for (int k = 0; k < WIENER_PF; ++k)
             if (f + k < f1)
@@ -279,9 +291,9 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
     if (blockIdx.x * 64 + threadIdx.x >= NBINS)
         return;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < NS; ++s)
     {
-        float *o = part + ((size_t)(chunk * 4 + s) * 5) * NBINS + b;
+        float *o = part + ((size_t)(chunk * 4 + s0 + s) * 5) * NBINS + b;
         o[0] = r00[s];
         o[NBINS] = r01x[s];
         o[2 * NBINS] = r01y[s];
