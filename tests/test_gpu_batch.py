@@ -110,6 +110,29 @@ def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path):
         alone.close()
 
 
+def test_activation_planes_follow_the_data_range(pkg, po, tmp_path):
+    """The plane GEMMs take every activation row as two fp16 planes of the row scaled by a power of two (csrc/gemm_planes.h):
+    the scale follows the row, so a near-silent track (1e-5 of full scale, where a fixed-range fp16 split would be all
+    subnormals) and an over-driven one (x30) must both stay within the parity tolerance RELATIVE to their own level,
+    in the same batch."""
+    hidden, N = 128, 24 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(hidden, seed=59), hidden, compress=False)
+    om = po.Model.load(path)
+    base = pkg.ggml.synth_audio(N, 901)
+    gains = [1e-5, 1.0, 30.0]
+    eng = pkg.Engine.from_file(path, N, tracks=3)
+    got = eng.infer_batch([(base * g).astype(np.float32) for g in gains], pkg.FLAG_DEBUG_TAPS)
+    fc1 = [eng.tap(f"fc1#{b}", 1) for b in range(3)]
+    eng.close()
+    for b, g in enumerate(gains):
+        ref, taps = po.umx_inference(om, (base * g).astype(np.float32), n_buf=N, want_taps=True)
+        assert rel_l2(fc1[b], taps["fc1_out"][1]) < TOL_STAGE, (g, "fc1")
+        for t in range(4):
+            scale = max(float(np.abs(ref[t]).max()), 1e-30)
+            assert float(np.abs(got[b][t] - ref[t]).max()) / scale < 2e-4, (g, t)
+
+
 def test_batched_kernel_agrees_with_single_track_kernel(pkg, tmp_path):
     """Same track through the single-track (VALU) kernel and the batched (matrix-core) kernel: different summation
     order, so not bitwise -- but far inside the parity tolerance."""
