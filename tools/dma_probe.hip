@@ -1,0 +1,83 @@
+// tools/dma_probe.hip -- L2 -> LDS bandwidth of `buffer_load_dwordx4 ... lds` by the shape of a wave-instruction:
+//   half:  16 rows x 64 B  (what gemm_planes.h issues: one 32-k slice of a row = half a 128-byte line)
+//   full:   8 rows x 128 B (whole lines)
+// The source is a matrix of `rows` x 2 KiB rows; every workgroup sweeps its own 256-row band K slice by K slice, like
+// the GEMM's A operand; bands are re-read `reps` times so that the data comes from the L2 / MALL, not HBM.
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/dma_probe tools/dma_probe.hip ; run: tools/dma_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef __attribute__((address_space(3))) void *lds_ptr;
+
+template <int FULL> __global__ __launch_bounds__(1024) void probe(const unsigned short *src, int row_bytes, int reps, unsigned *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(src), 0, 0x7fffffff, 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    const long band = (long)blockIdx.x * 256 * row_bytes;
+    // per stage: 256 rows x 128 B = 32 KB (two 32-k slices of one plane, or one slice of two planes)
+    const int voff = FULL ? (lane >> 3) * row_bytes + (lane & 7) * 16 : (lane >> 2) * row_bytes + (lane & 3) * 16;
+    unsigned acc = 0;
+    for (int r = 0; r < reps; ++r)
+        for (int k0 = 0; k0 < row_bytes; k0 += 128)
+        {
+            const int buf = ((k0 >> 7) & 1) * 32768;
+            if (FULL)
+            {
+                // 32 groups of 8 rows; 16 waves -> 2 instructions per wave
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                {
+                    const int g = wave + 16 * i;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(size_t)(lds0 + buf + g * 1024), 16, voff,
+                                                             (int)(band + (long)g * 8 * row_bytes + k0), 0, 0);
+                }
+            }
+            else
+            {
+                // 2 slices x 16 groups of 16 rows; 16 waves -> 2 instructions per wave
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(size_t)(lds0 + buf + i * 16384 + wave * 1024), 16, voff,
+                                                             (int)(band + (long)wave * 16 * row_bytes + k0 + 64 * i), 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70 | 2); // one stage in flight
+            acc += smem[(lane * 16 + k0) & 65535];
+        }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (acc == 0x12345678u)
+        *sink = acc;
+}
+
+int main()
+{
+    const int row_bytes = 2048, rows = 256 * 256, reps = 8; // 128 MiB source: L2 + MALL resident after the first sweep
+    unsigned short *src;
+    unsigned *sink;
+    hipMalloc(&src, (size_t)rows * row_bytes);
+    hipMalloc(&sink, 4);
+    hipMemset(src, 1, (size_t)rows * row_bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int full = 0; full < 2; ++full)
+        for (int it = 0; it < 3; ++it)
+        {
+            hipEventRecord(e0);
+            if (full)
+                hipLaunchKernelGGL(probe<1>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, reps, sink);
+            else
+                hipLaunchKernelGGL(probe<0>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, reps, sink);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("%s lines: %.3f ms, %.2f TB/s into LDS\n", full ? "full (8 rows x 128 B)" : "half (16 rows x 64 B)", ms,
+                   (double)rows * row_bytes * reps / (ms * 1e-3) / 1e12);
+        }
+    return 0;
+}
