@@ -133,6 +133,37 @@ def test_activation_planes_follow_the_data_range(pkg, po, tmp_path):
             assert float(np.abs(got[b][t] - ref[t]).max()) / scale < 2e-4, (g, t)
 
 
+def test_production_configuration_at_full_size_against_the_oracle(pkg, po, tmp_path):
+    """What `bench.py` times by default, value-checked: UMX-L width, the full 60 s segment (T = 2584), several track lanes
+    in one context -- 256 x 256 plane-GEMM tiles that straddle lanes, the batched matrix-core recurrence, the fused
+    Wiener / inverse-STFT kernel -- every stage tap and the stems of every lane against the oracle, two carried
+    segments for one lane."""
+    hidden, N, B = 1024, pkg.SEGMENT_SAMPLES, 3
+    path = str(tmp_path / "m.bin.gz")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(hidden, seed=61), hidden)
+    om = po.Model.load(path)
+    eng = pkg.Engine.from_file(path, N, tracks=B)
+    assert eng.T == 2584 and eng.lstm_is_batched()
+    waves = [[pkg.ggml.synth_audio(N if b != 1 else N - 12345, 300 + 10 * b + s) for s in range(2)] for b in range(B)]
+    states = [po.stream_state(hidden) for _ in range(B)]
+    for s in range(2):
+        batch = [waves[b][s] if (s == 0 or b == 0) else None for b in range(B)]  # second call: lane 0 only
+        got = eng.infer_batch(batch, pkg.FLAG_DEBUG_TAPS)
+        assert eng.lstm_was_persistent()
+        for b in range(B):
+            if batch[b] is None:
+                continue
+            ref, taps = po.umx_inference(om, batch[b], n_buf=N, state=states[b], want_taps=True)
+            for t in range(4):
+                for name, key, tol in (("fc1", "fc1_out", TOL_STAGE), ("lstm", "lstm_out", TOL_STAGE), ("fc2", "fc2_out", TOL_STAGE),
+                                       ("mask", "mask", TOL_STAGE), ("target_mag", "target_mag", TOL_STAGE), ("y", "y", 2e-4)):
+                    err = rel_l2(eng.tap(f"{name}#{b}", t), taps[key][t])
+                    assert err < tol, (s, b, t, name, err)
+                assert float(np.abs(got[b][t] - ref[t]).max()) < TOL_WAVE, (s, b, t)
+            assert rel_l2(eng.track_stream_get(b), states[b]) < TOL_STAGE, (s, b)
+    eng.close()
+
+
 def test_batched_kernel_agrees_with_single_track_kernel(pkg, tmp_path):
     """Same track through the single-track (VALU) kernel and the batched (matrix-core) kernel: different summation
     order, so not bitwise -- but far inside the parity tolerance."""
