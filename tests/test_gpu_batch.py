@@ -75,7 +75,8 @@ def test_track_bits_do_not_depend_on_lane_companions_or_batch_size(pkg, tmp_path
                 assert (outs[s][t] == ref_outs[s][t]).all(), (B, lane, flags, s, t)
 
 
-def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path):
+@pytest.mark.parametrize("flags", [0, 0x1, 0x700], ids=["config3", "config2_no_wiener", "config1_vocals_only"])
+def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path, flags):
     """Lanes follow each other every T rows in the lane-contiguous activation buffers, so the 128- / 256-row tiles of the
     plane GEMMs hold rows of two lanes whenever T is not a multiple of the tile (the production T = 2584 is not): 301
     frames, three lanes of different audio, one of them absent in the second call.  Per lane: the oracle's answer, the
@@ -92,8 +93,8 @@ def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path):
         batch = [waves[b][s] for b in range(B)]
         if s == 1:
             batch[1] = None  # lane 1 sits the second call out
-        got.append(eng.infer_batch(batch, pkg.FLAG_DEBUG_TAPS))
-        masks.append([None if batch[b] is None else eng.tap(f"mask#{b}", 2) for b in range(B)])
+        got.append(eng.infer_batch(batch, pkg.FLAG_DEBUG_TAPS | flags))
+        masks.append([None if batch[b] is None else eng.tap(f"mask#{b}", 3) for b in range(B)])
     eng.close()
     for b in range(B):
         st = po.stream_state(hidden)
@@ -101,12 +102,12 @@ def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path):
         for s in range(NSEG):
             if s == 1 and b == 1:
                 continue
-            ref, taps = po.umx_inference(om, waves[b][s], n_buf=N, state=st, want_taps=True)
-            one = alone.infer_batch([waves[b][s]])[0]
+            ref, taps = po.umx_inference(om, waves[b][s], n_buf=N, state=st, flags=flags, want_taps=True)
+            one = alone.infer_batch([waves[b][s]], flags)[0]
             for t in range(4):
                 assert float(np.abs(got[s][b][t] - ref[t]).max()) < TOL_WAVE, (b, s, t)
                 assert (got[s][b][t] == one[t]).all(), (b, s, t)
-            assert rel_l2(masks[s][b], taps["mask"][2]) < TOL_STAGE, (b, s)
+            assert rel_l2(masks[s][b], taps["mask"][3]) < TOL_STAGE, (b, s)
         alone.close()
 
 
