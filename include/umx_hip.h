@@ -88,17 +88,18 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
  * UMX_CREATE_GEMM_F32 (environment UMX_GEMM=f32) selects the fp32-MFMA kernels (exact fp32 FMA chain) instead. */
 #define UMX_CREATE_GEMM_F32 0x4u
 /* u8-resident weights (fc1, W_ih; W_hh in the batched LSTM kernel) on the bf16 matrix cores: q - 128 is an integer in
- * [-128, 127] and EXACT in bf16, so by default the weight is ONE bf16 term (three products with the split activation
- * instead of six) and the affine map of model.cpp:610-616 is applied to the accumulated sum:
+ * [-128, 127] and EXACT in bf16 and fp16, so by default the weight is ONE term (three products with the bf16-split
+ * activation instead of six; two with the fp16 planes of csrc/gemm_planes.h) and the affine map of model.cpp:610-616 is applied to the accumulated sum:
  *     sum_k a_k (q_k s + o) = s sum_k a_k (q_k - 128) + (o + 128 s) sum_k a_k.
  * The reference rounds q*s+o to fp32 per weight first; the two differ by exactly that rounding (~1e-7 of the dot
  * product, the size of one fp32 rounding of the sum).  UMX_CREATE_U8_DEQUANT (environment UMX_U8=dequant) keeps the
  * per-weight form (dequantise, split in three, six products): bit-identical to UMX_CREATE_DEQUANTISE_AT_LOAD. */
 #define UMX_CREATE_U8_DEQUANT 0x20u
-/* The bf16 GEMM flavour exists in two forms.  csrc/gemm_planes.h (default of track-batched contexts): every activation
- * matrix is split once into three bf16 planes (+ row sums) by a small kernel, every weight matrix is re-encoded once
- * at load time as exact bf16 integer planes (u8: 1, u16: 2; fp32: 3 split terms), and the GEMM itself only moves
- * 256 x 256 tiles global -> LDS by DMA, over all track lanes at once, and issues matrix-core instructions.
+/* The split-operand GEMM flavour exists in two forms.  csrc/gemm_planes.h (default of track-batched contexts): every
+ * activation matrix is split once, by a small kernel, into TWO fp16 planes of the row scaled by a power of two (+ row
+ * sums and inverse scales), every weight matrix is re-encoded once at load time as exact fp16 integer planes (u8: 1,
+ * u16: 2; fp32: 2 split terms), and the GEMM itself only moves 256 x 256 tiles global -> LDS by DMA, over all track lanes
+ * at once, and issues matrix-core instructions (2 products per fp32 product for u8 weights, 4 for u16).
  * csrc/gemm_bf16x3.h (default of single-track contexts): keeps u8 / u16 weights as stored and splits both operands while
  * staging every 128 x 128 tile; small enough in registers and LDS to share the CUs with the two co-resident single-track
  * LSTM grids of the latency pipeline.  UMX_CREATE_GEMM_STAGED / UMX_CREATE_GEMM_PLANES (environment UMX_GEMM=bf16x3 /
@@ -112,8 +113,8 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
  * not by arithmetic.  A context created for n_tracks (1..16) independent tracks holds that many "track lanes", each
  * with its own streaming LSTM state (= its own std::array<lstm_data,4>, umx.cpp:167-171) and activation buffers;
  * umx_hip_infer_batch* runs one segment of every lane per call, and the recurrence of all lanes is ONE launch per
- * layer in which W_hh.h is a matrix-matrix product on the bf16 matrix cores (three-term split, fp32 accumulate:
- * csrc/lstm_batch.h).  The LSTM flavour is fixed per context: n_tracks > 1 (or UMX_CREATE_LSTM_BATCHED, environment
+ * layer in which W_hh.h is a matrix-matrix product on the matrix cores (u8 W_hh as one exact fp16 plane against two fp16
+ * planes of h, fp32 accumulate: csrc/lstm_batch.h).  The LSTM flavour is fixed per context: n_tracks > 1 (or UMX_CREATE_LSTM_BATCHED, environment
  * UMX_LSTM=batched, on a 1-track context) selects the batched kernel for every call, so a track's result never
  * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
  * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise. */
