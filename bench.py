@@ -118,9 +118,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--tracks", type=int, default=16,
-                    help="independent tracks per GPU run together (track lanes, 1..16): one step = one 60 s segment of EVERY "
-                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4)")
+    ap.add_argument("--tracks", type=int, default=32,
+                    help="independent tracks per GPU run together (track lanes, 1..48): one step = one 60 s segment of EVERY "
+                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4), > 16 its form that takes groups "
+                         "of 16 lanes in turn (csrc/lstm_batch2.h)")
     ap.add_argument("--batched-lstm", action="store_true", help="use the batched LSTM kernel also with --tracks 1")
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--segment-samples", type=int, default=SEG)
@@ -334,8 +335,9 @@ def main():
         lstm_alg = rec * B
         if batched:
             lp = 2 if (not args.expanded_weights and not args.u8_dequant) else 6  # u8 W_hh: 1 fp16 plane x 2 fp16 planes of h
-            lstm_issued = rec * 16 * lp * (1.25 if lp == 2 else 1.0)  # 16 tracks wide whatever B; + the all-ones tile of the u8 form
-            lname = "lstm_batch_kernel"
+            groups = (B + 15) // 16  # the matrix instruction is 16 tracks wide: one MFMA phase per group of 16 lanes
+            lstm_issued = rec * 16 * groups * lp * (1.25 if lp == 2 else 1.0)  # + the all-ones tile of the u8 form
+            lname = "lstm_batch_kernel" if groups == 1 else "lstm_batch2_kernel"
         else:
             lstm_issued = lstm_alg
             lname = "lstm_persistent_kernel" if lstm_mode >= 1 else "lstm_step_kernel"
@@ -352,7 +354,7 @@ def main():
                         "tracks_per_serial_step": B,
                         "note": "3*T serially dependent steps per segment; priced against the fp32 roof on ALGORITHMIC flops (2*T*Hl*4Hl*8 chains*tracks), "
                                 "frac_latency = measured cross-CU hand-off floor (tools/handoff_probe.hip) / step time",
-                        "traffic": find_traffic("lstm_batch" if batched else "lstm_persistent")})
+                        "traffic": find_traffic(("lstm_batch2" if B > 16 else "lstm_batch_kernel") if batched else "lstm_persistent")})
 
         def stream_entry(key, name, nbytes, tneedle):
             ms = stage_ms.get(key, 0.0) / B
@@ -404,7 +406,7 @@ def main():
                                     "seeded synthetic 44.1 kHz stereo, synthetic UMX-L-shaped u8/u16 ggml weights"),
                        "hidden": H, "segment_samples": N, "frames": T, "stems": 4, "tracks_per_gpu": B,
                        "audio_seconds_per_step": B * seg_sec,
-                       "lstm_kernel": ("batched, matrix cores (lstm_batch_kernel)" if batched else "single-track, VALU (lstm_persistent_kernel)"),
+                       "lstm_kernel": (("batched, matrix cores, groups of 16 lanes in turn (lstm_batch2_kernel)" if B > 16 else "batched, matrix cores (lstm_batch_kernel)") if batched else "single-track, VALU (lstm_persistent_kernel)"),
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
                        "gemm": (flavour + (" (fp16 matrix cores, f32 accumulate: activations split once into 2 fp16 planes of the power-of-two "
                                            "scaled row, u8 weights exact in 1 plane (2 products), u16 weights exact in 2 planes (4 products), "

@@ -119,7 +119,7 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
  * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
  * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise. */
 #define UMX_CREATE_LSTM_BATCHED 0x10u
-#define UMX_MAX_TRACKS 16
+#define UMX_MAX_TRACKS 48 /* more than 16 need a quantised model with its u8 W_hh resident (groups of 16 lanes, csrc/lstm_batch2.h) */
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                           const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
 int umx_hip_n_tracks(const umx_hip_ctx *ctx);

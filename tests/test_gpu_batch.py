@@ -56,13 +56,15 @@ def test_track_bits_do_not_depend_on_lane_companions_or_batch_size(pkg, tmp_path
     path = str(tmp_path / "m.bin")
     pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=43), H, compress=False)
     track = [pkg.ggml.synth_audio(N, 900 + s) for s in range(NSEG)]
-    other = [pkg.ggml.synth_audio(N, 950 + i) for i in range(16)]
+    other = [pkg.ggml.synth_audio(N, 950 + i) for i in range(48)]
     results = []
-    for B, lane, flags in ((1, 0, 0), (4, 2, 0), (16, 13, 0), (4, 1, pkg.FLAG_LSTM_STEPWISE), (4, 3, pkg.FLAG_LSTM_FORCE_SAFE)):
+    for B, lane, flags in ((1, 0, 0), (4, 2, 0), (16, 13, 0), (4, 1, pkg.FLAG_LSTM_STEPWISE), (4, 3, pkg.FLAG_LSTM_FORCE_SAFE),
+                           (32, 5, 0), (32, 29, 0), (20, 17, pkg.FLAG_LSTM_STEPWISE), (24, 21, pkg.FLAG_LSTM_FORCE_SAFE),  # > 16: lstm_batch2.h
+                           (48, 44, 0), (40, 35, pkg.FLAG_LSTM_STEPWISE)):
         eng = pkg.Engine.from_file(path, N, tracks=B, lstm_batched=True)
         outs = []
         for s in range(NSEG):
-            batch = [other[(i + s) % 16] for i in range(B)]
+            batch = [other[(i + s) % 48] for i in range(B)]
             batch[lane] = track[s]
             outs.append(eng.infer_batch(batch, flags)[lane])
         results.append((outs, eng.track_stream_get(lane), B, lane, flags))
@@ -218,7 +220,7 @@ def test_idle_lane_keeps_its_state_and_lanes_reset_independently(pkg, model_smal
         eng.infer_batch([None, None, None])
     eng.close()
     with pytest.raises(RuntimeError):
-        pkg.Engine(targets, 128, N, tracks=17)
+        pkg.Engine(targets, 128, N, tracks=pkg.MAX_TRACKS + 1)
 
 
 def test_whole_tracks_as_track_lanes_and_the_batch_cli(pkg, po, tmp_path):

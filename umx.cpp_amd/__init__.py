@@ -141,7 +141,7 @@ CREATE_LSTM_BATCHED = 0x10
 CREATE_U8_DEQUANT = 0x20
 CREATE_GEMM_STAGED = 0x40
 CREATE_GEMM_PLANES = 0x80
-MAX_TRACKS = 16
+MAX_TRACKS = 48
 
 HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "umx_hip_n_tracks", "umx_hip_lstm_is_batched",
                "umx_hip_track_stream_reset", "umx_hip_track_stream_get", "umx_hip_track_stream_set",

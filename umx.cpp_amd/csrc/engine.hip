@@ -27,6 +27,7 @@
 #include "gemm_planes.h"
 #include "lstm_kernels.h"
 #include "lstm_batch.h"
+#include "lstm_batch2.h"
 #include "track_kernels.h"
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
@@ -203,6 +204,20 @@ template <int HL> static const void *lstm_batch_fn_hl(bool wq, bool precise)
               : (precise ? reinterpret_cast<const void *>(lstm_batch_kernel<HL, false, true>)
                          : reinterpret_cast<const void *>(lstm_batch_kernel<HL, false, false>));
 }
+template <int G> static const void *lstm_batch2_fn_g(int Hl, bool precise)
+{
+    switch (Hl)
+    {
+    case 64: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<64, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<64, G, false>);
+    case 128: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<128, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<128, G, false>);
+    case 256: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<256, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<256, G, false>);
+    case 512: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<512, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<512, G, false>);
+    default: return nullptr;
+    }
+}
+// two or three groups of 16 lanes (lstm_batch2.h): u8-resident W_hh only
+static const void *lstm_batch2_fn(int Hl, int groups, bool precise) { return groups == 3 ? lstm_batch2_fn_g<3>(Hl, precise) : lstm_batch2_fn_g<2>(Hl, precise); }
+static int lstmb2_bulk(int groups) { return groups == 3 ? 2 : 4; } // ring rows per fetch: what fits the LDS beside the partial sums
 static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
 {
     switch (Hl)
@@ -334,8 +349,8 @@ struct umx_hip_ctx
     int ph_next = -1; // -1: no phased segment open; 0..2: next LSTM layer; 3: back stage pending
     int ph_n = 0;
     unsigned ph_flags = 0;
-    int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask);
-    int run_lstm_layer_batched(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask);
+    int run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned long long lane_mask);
+    int run_lstm_layer_batched(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned long long lane_mask);
     int sync_all();
     void launch_gemm(Lane &ln, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
     int stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active, int nact);
@@ -921,7 +936,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         return rc;
     if (int rc = dalloc(&backup, (size_t)kBackupCalls * 3 * state_floats() * B))
         return rc;
-    lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) : (size_t)0);
+    lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) * ((B + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS) : (size_t)0);
     if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
         lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
     nslots = 2;
@@ -1049,7 +1064,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         if (lstm_batched)
         {
             // the batched kernel: worst-case dynamic LDS (16 lanes), both activation flavours
-            const size_t lds_max = lstmb_lds_bytes(LSTMB_MAX_TRACKS, 8);
+            const size_t lds_max = lstmb_lds_bytes(LSTMB_GROUP_TRACKS, 8);
             per_cu = 1 << 30;
             for (int precise = 0; precise < 2; ++precise)
                 for (int wq = 0; wq < 2; ++wq)
@@ -1065,6 +1080,25 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                     UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstmb_lds_bytes(B > 8 ? 16 : B > 4 ? 8 : B > 2 ? 4 : B > 1 ? 2 : 1, B > 8 ? 8 : 16)));
                     per_cu = std::min(per_cu, v);
                 }
+            if (B > LSTMB_GROUP_TRACKS) // more than 16 lanes: the two-group kernel (u8-resident W_hh only)
+            {
+                for (int l = 0; l < 3; ++l)
+                    if (!whh_q[l] || u8_dequant)
+                    {
+                        set_error("more than 16 track lanes need the u8-resident W_hh (quantised model, no UMX_CREATE_U8_DEQUANT / _DEQUANTISE_AT_LOAD)");
+                        return UMX_ERR_ARG;
+                    }
+                for (int groups = 2; groups <= 3; ++groups)
+                    for (int precise = 0; precise < 2; ++precise)
+                    {
+                        const void *fn = lstm_batch2_fn(Hl, groups, precise != 0);
+                        const size_t l2 = lstmb2_lds_bytes(groups, lstmb2_bulk(groups));
+                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+                        int v = 0;
+                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTMB2_THREADS, l2));
+                        per_cu = std::min(per_cu, v);
+                    }
+            }
             lstm_batch_capacity = per_cu * cus;
         }
     }
@@ -1137,7 +1171,7 @@ int umx_hip_ctx::sync_all()
 }
 
 // ---------------------------------------------------------------- LSTM layer
-int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask)
+int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned long long lane_mask)
 {
     if (lstm_batched)
         return run_lstm_layer_batched(sl, layer, active, nact, stepwise, lane_mask);
@@ -1235,7 +1269,7 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
 
 // All track lanes of `lane_mask` through ONE launch per layer (lstm_batch.h).  stepwise (or a grid that cannot be
 // co-resident): the same kernel one step per launch, carried through the fp32 stream state -- bit-identical.
-int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned lane_mask)
+int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, int nact, bool stepwise, unsigned long long lane_mask)
 {
     hipStream_t st = sl.stream;
     LstmBArgs a;
@@ -1274,13 +1308,15 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     a.lane_mask = lane_mask;
     int top = 0;
     for (int ln = 0; ln < LSTMB_MAX_TRACKS; ++ln)
-        if ((lane_mask >> ln) & 1u)
+        if ((lane_mask >> ln) & 1ull)
             top = ln + 1;
+    const int groups = (top + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS; // > 1: lstm_batch2.h, groups of 16 lanes in turn
     a.nbp = top > 8 ? 16 : top > 4 ? 8 : top > 2 ? 4 : top > 1 ? 2 : 1;
-    a.bulk = a.nbp > 8 ? 8 : 16;
-    const size_t lds = lstmb_lds_bytes(a.nbp, a.bulk);
+    a.bulk = groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
+    const size_t lds = groups > 1 ? lstmb2_lds_bytes(groups, a.bulk) : lstmb_lds_bytes(a.nbp, a.bulk);
     const bool wq = whh_q[layer] != nullptr && !u8_dequant;
-    const void *fn = lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
+    const void *fn = groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT) : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
+    const int threads = groups > 1 ? LSTMB2_THREADS : LSTM_THREADS;
     void *kargs[] = {&a};
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
     if (persistent)
@@ -1293,7 +1329,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         a.abort_at = ((last_flags & UMX_FLAG_DEBUG_LSTM_ABORT) && layer == 1) ? T / 2 : 0;
         UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (clear ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
         hipError_t e = lstm_gate_launch(device, st, 8 * S * 2, 2 * n_cus,
-                                        [&] { return hipLaunchKernel(fn, dim3(8 * S), dim3(LSTM_THREADS), kargs, lds, st); });
+                                        [&] { return hipLaunchKernel(fn, dim3(8 * S), dim3(threads), kargs, lds, st); });
         if (e != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1309,7 +1345,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         {
             a.t_begin = step;
             a.t_end = step + 1;
-            UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * S), dim3(LSTM_THREADS), kargs, lds, st));
+            UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * S), dim3(threads), kargs, lds, st));
         }
     }
     sl.last_persistent = persistent;
@@ -1711,7 +1747,7 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
         set_error("infer: need 1 <= n_tracks <= the context's track count and non-null argument arrays");
         return UMX_ERR_ARG;
     }
-    unsigned lane_mask = 0;
+    unsigned long long lane_mask = 0;
     for (int ln = 0; ln < nb; ++ln)
     {
         if (!audio_dev[ln]) // idle lane: its stream state stays as it is
@@ -1727,7 +1763,7 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
                 set_error("infer_segment: null output pointer");
                 return UMX_ERR_ARG;
             }
-        lane_mask |= 1u << ln;
+        lane_mask |= 1ull << ln;
     }
     if (!lane_mask)
     {

@@ -40,7 +40,8 @@
 namespace umx
 {
 
-constexpr int LSTMB_MAX_TRACKS = 16;
+constexpr int LSTMB_MAX_TRACKS = 48;  // track lanes per context: 16 per launch of this kernel, two or three groups of 16 in lstm_batch2.h
+constexpr int LSTMB_GROUP_TRACKS = 16; // the matrix instruction's N
 // x64 shader cycles a wave sleeps before its first poll of a step.  A wave that also runs the gate phase has just
 // published and needs one hand-off latency; the other waves come straight from the barrier and have the whole gate
 // phase in front of them -- polling through it would only load the L2 (every failed attempt is 8 x 16 B per lane)
@@ -79,7 +80,7 @@ struct LstmBArgs
     int tmap[4];
     int force_safe;
     unsigned tag_epoch; // a granule's tag is (epoch << 12) | (step + 1): unique per launch (20 bits of epoch)
-    unsigned lane_mask; // bit n = track lane n takes part in this launch
+    unsigned long long lane_mask; // bit n = track lane n takes part in this launch
     int nbp;            // lanes the LDS arrays are sized for: power of two >= highest active lane + 1
     int bulk;           // W_ih-row ring: rows per bulk fetch (ring = 2 * bulk rows)
     int t_begin, t_end; // steps of this launch
