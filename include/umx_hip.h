@@ -117,7 +117,9 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
  * planes of h, fp32 accumulate: csrc/lstm_batch.h).  The LSTM flavour is fixed per context: n_tracks > 1 (or UMX_CREATE_LSTM_BATCHED, environment
  * UMX_LSTM=batched, on a 1-track context) selects the batched kernel for every call, so a track's result never
  * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
- * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise. */
+ * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise.
+ * More than 16 lanes (up to UMX_MAX_TRACKS): one workgroup serves groups of 16 lanes in turn (csrc/lstm_batch2.h), the
+ * same bits per track; needs the u8-resident W_hh of a quantised model. */
 #define UMX_CREATE_LSTM_BATCHED 0x10u
 #define UMX_MAX_TRACKS 48 /* more than 16 need a quantised model with its u8 W_hh resident (groups of 16 lanes, csrc/lstm_batch2.h) */
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
