@@ -230,7 +230,7 @@ def main():
 
     # ---- value_pcie: pinned host buffers in and out, the same number of steps timed the same way
     dt_pcie = None
-    if not args.no_pcie:
+    if not args.no_pcie and world == 1:  # an N = 1 figure, like cpu_baseline (and an exception on one rank must not leave the others at a barrier)
         try:
             h_in = [torch.from_numpy(w).pin_memory() for w in waves]
             h_out = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4 * B)] for _ in range(2)]
