@@ -358,6 +358,11 @@ __device__ __forceinline__ void wiener_expand(float4 rc, float2 (&Rr)[2][2])
     Rr[1][1] = make_float2(rc.w, 0.f);
 }
 
+// Both functions are the generic complex 2x2 arithmetic of wiener_apply_kernel with the structural zeros taken out: R_j,
+// Cxx and its inverse are Hermitian with exactly real diagonals (above), so every product with an exact zero and every
+// sum with one is dropped -- x * 0 is a zero and y + 0 is y, so the VALUES are those of the generic form (only the sign
+// of a zero can differ), at about half the instructions; the remaining operations keep the generic form's order and
+// rounding.  tests/test_gpu_parity.py compares the fused kernel against wiener_apply_kernel bit for bit.
 __device__ __forceinline__ void wiener_bin_setup(float2 X0, float2 X1, const float (&m0)[4], const float (&m1)[4],
                                                  const float4 (&rc)[4], float max_abs, float rmax, WienerBin &w)
 {
@@ -365,7 +370,7 @@ __device__ __forceinline__ void wiener_bin_setup(float2 X0, float2 X1, const flo
     w.x0 = make_float2(div_by(X0.x, max_abs, rmax), div_by(X0.y, max_abs, rmax)); // wiener.cpp:118-130
     w.x1 = make_float2(div_by(X1.x, max_abs, rmax), div_by(X1.y, max_abs, rmax));
     const float2 p0 = unit_phasor(X0), p1 = unit_phasor(X1);
-    float2 C[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
+    float c00 = 0.f, c11 = 0.f, c01x = 0.f, c01y = 0.f; // Cxx = [[c00, c01], [conj(c01), c11]]
 #pragma unroll
     for (int s = 0; s < 4; ++s)
     {
@@ -375,51 +380,42 @@ __device__ __forceinline__ void wiener_bin_setup(float2 X0, float2 X1, const flo
         float sum = 0.f;
         sum += (ra * ra) + (0.f * 0.f);
         sum += (rb * rb) + (0.f * 0.f);
-        w.v[s] = sum / 2;
-        float2 Rr[2][2];
-        wiener_expand(rc[s], Rr);
-#pragma unroll
-        for (int c1 = 0; c1 < 2; ++c1)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-            { // wiener.cpp:307-325: Cxx += reg(c1,c2) + v * R   (F6: once per source)
-                const float2 term = make_float2((c1 == c2 ? reg : 0.f) + w.v[s] * Rr[c1][c2].x, 0.f + w.v[s] * Rr[c1][c2].y);
-                C[c1][c2].x += term.x;
-                C[c1][c2].y += term.y;
-            }
+        const float v = sum / 2;
+        w.v[s] = v;
+        // wiener.cpp:307-325: Cxx += reg(c1,c2) + v * R   (F6: once per source)
+        c00 += reg + v * rc[s].x;
+        c01x += v * rc[s].y;
+        c01y += v * rc[s].z;
+        c11 += reg + v * rc[s].w;
     }
-    // invert4D wiener.cpp:54-84
-    const float2 det = csub(cmul(C[0][0], C[1][1]), cmul(C[0][1], C[1][0]));
-    const float nrm = det.x * det.x + det.y * det.y;
-    const float2 invDet = make_float2(det.x / nrm, -det.y / nrm);
-    const float2 nInv = make_float2(-invDet.x, -invDet.y);
-    const float2 i00 = cmul(invDet, C[1][1]), i01 = cmul(nInv, C[0][1]), i11 = cmul(invDet, C[0][0]);
-    w.ci00 = i00.x;
-    w.ci01x = i01.x;
-    w.ci01y = i01.y;
-    w.ci11 = i11.x;
+    // invert4D wiener.cpp:54-84: det = c00 c11 - c01 conj(c01) is real; 1/det is formed as det / |det|^2 like the generic form
+    const float det = c00 * c11 - (c01x * c01x + c01y * c01y);
+    const float idet = det / (det * det);
+    w.ci00 = idet * c11;
+    w.ci01x = -idet * c01x;
+    w.ci01y = -idet * c01y;
+    w.ci11 = idet * c00;
 }
 
-// y_s = G_s x * max_abs for one source (wiener.cpp:343-400)
+// y_s = G_s x * max_abs for one source (wiener.cpp:343-400): G = (R Cxx^-1) v, R = [[a, b], [conj(b), d]], Cxx^-1 = [[p, q], [conj(q), r]]
 __device__ __forceinline__ void wiener_bin_apply(const WienerBin &w, int s, float4 rc, float max_abs, float2 (&o)[2])
 {
     const float vs = s == 0 ? w.v[0] : s == 1 ? w.v[1] : s == 2 ? w.v[2] : w.v[3]; // selects: w stays in registers
-    float2 Rr[2][2];
-    wiener_expand(rc, Rr);
-    const float2 Ci[2][2] = {{make_float2(w.ci00, 0.f), make_float2(w.ci01x, w.ci01y)},
-                             {make_float2(w.ci01x, -w.ci01y), make_float2(w.ci11, 0.f)}};
+    const float a = rc.x, bx = rc.y, by = rc.z, d = rc.w, p = w.ci00, qx = w.ci01x, qy = w.ci01y, r = w.ci11;
     float2 g[2][2];
+    // g00 = a p + b conj(q)
+    g[0][0] = make_float2(a * p + (bx * qx + by * qy), by * qx - bx * qy);
+    // g01 = a q + b r
+    g[0][1] = make_float2(a * qx + bx * r, a * qy + by * r);
+    // g10 = conj(b) p + d conj(q)
+    g[1][0] = make_float2(bx * p + d * qx, -(by * p + d * qy));
+    // g11 = conj(b) q + d r
+    g[1][1] = make_float2((bx * qx + by * qy) + d * r, bx * qy - by * qx);
 #pragma unroll
     for (int c1 = 0; c1 < 2; ++c1)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
-        {
-            float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int c3 = 0; c3 < 2; ++c3)
-                acc = cadd(acc, cmul(Rr[c1][c3], Ci[c3][c2]));
-            g[c1][c2] = make_float2(acc.x * vs, acc.y * vs);
-        }
+            g[c1][c2] = make_float2(g[c1][c2].x * vs, g[c1][c2].y * vs);
     o[0] = make_float2(0.f, 0.f);
     o[1] = make_float2(0.f, 0.f);
 #pragma unroll
