@@ -27,7 +27,8 @@ int main(int argc, const char **argv)
         return 1;
     }
     const std::string model_file = argv[1], out_dir = argv[2];
-    const int nfiles = argc - 3, lanes = std::min(nfiles, UMX_MAX_TRACKS);
+    const int nfiles = argc - 3;
+    int lanes = std::min(nfiles, UMX_MAX_TRACKS);
     char err[UMX_ERRLEN] = "";
     umx_model *model = nullptr;
     if (umx_model_load(model_file.c_str(), &model, err)) // umx.cpp:63-70
@@ -36,8 +37,15 @@ int main(int argc, const char **argv)
         return 1;
     }
     umx_hip_ctx *ctx = nullptr;
-    if (umx_hip_create_tracks(&ctx, env_int("UMX_DEVICE", 0), umx_model_hidden(model), UMX_SEGMENT_SAMPLES, umx_model_views(model),
-                              umx_model_n_tensors(model), 0, lanes))
+    int rc = umx_hip_create_tracks(&ctx, env_int("UMX_DEVICE", 0), umx_model_hidden(model), UMX_SEGMENT_SAMPLES, umx_model_views(model),
+                                   umx_model_n_tensors(model), 0, lanes);
+    if (rc && lanes > 16) // more than 16 lanes need the u8-resident W_hh of a quantised model: an f32 model gets 16
+    {
+        lanes = 16;
+        rc = umx_hip_create_tracks(&ctx, env_int("UMX_DEVICE", 0), umx_model_hidden(model), UMX_SEGMENT_SAMPLES, umx_model_views(model),
+                                   umx_model_n_tensors(model), 0, lanes);
+    }
+    if (rc)
     {
         fprintf(stderr, "umx_hip_create_tracks: %s\n", umx_hip_last_error(nullptr));
         return 1;
