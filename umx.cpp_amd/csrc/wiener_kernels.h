@@ -271,22 +271,22 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
             r11[s] += (0.f + q11.x);
         }
     };
-    WienerFrame<NS> cur[WIENER_PF], nxt[WIENER_PF];
+    // a ring of PF frames in registers: a slot is refilled (frame + PF) as soon as its frame has been accumulated, so PF
+    // frames' loads are in flight at all times
+    constexpr int PF = NS == 1 ? 16 : NS == 2 ? 12 : WIENER_PF;
+    WienerFrame<NS> ringf[PF];
 #pragma unroll
-    for (int k = 0; k < WIENER_PF; ++k)
-        wiener_frame_load<NS>(cur[k], spec, mag, T, min(f0 + k, f1 - 1), b);
-    for (int f = f0; f < f1; f += WIENER_PF)
+    for (int k = 0; k < PF; ++k)
+        wiener_frame_load<NS>(ringf[k], spec, mag, T, min(f0 + k, f1 - 1), b);
+    for (int f = f0; f < f1; f += PF)
     {
 #pragma unroll
-        for (int k = 0; k < WIENER_PF; ++k) // the next group is in flight while this one is accumulated
-            wiener_frame_load<NS>(nxt[k], spec, mag, T, min(f + WIENER_PF + k, f1 - 1), b);
-#pragma unroll
-        for (int k = 0; k < WIENER_PF; ++k)
+        for (int k = 0; k < PF; ++k)
+        {
             if (f + k < f1)
-                accumulate(cur[k]);
-#pragma unroll
-        for (int k = 0; k < WIENER_PF; ++k)
-            cur[k] = nxt[k];
+                accumulate(ringf[k]);
+            wiener_frame_load<NS>(ringf[k], spec, mag, T, min(f + PF + k, f1 - 1), b);
+        }
     }
     if (blockIdx.x * 64 + threadIdx.x >= NBINS)
         return;
