@@ -5,22 +5,30 @@ A "step" = one pass of the hot path (umx_inference, inference.cpp:12-207) over o
 EVERY track lane of the context: STFT -> 4 x [fc1/bn/tanh -> 3-layer BiLSTM -> fc2 -> fc3 -> mask] -> Wiener EM ->
 4 x iSTFT.  Consecutive steps are consecutive segments of the same tracks: the streaming LSTM state carries over
 (umx.cpp:167-171).  The default workload is BASELINE config 3 (4 stems + Wiener, the full umx_inference) on
---tracks independent tracks per GPU (default 16: their LSTM recurrences share one matrix-core launch per layer,
+--tracks independent tracks per GPU (default 32: their LSTM recurrences share one matrix-core launch per layer,
 SURVEY 8f-4); --tracks 1 is the single-track, latency-optimised engine; --no-wiener gives config 2, --vocals-only
 config 1.
 
 What the JSON line holds (one line, rank 0):
-  value            audio-seconds per wall-second, whole job, inputs and stems RESIDENT IN HBM (the contract's number)
+  value            audio-seconds per wall-second, whole job, inputs and stems RESIDENT IN HBM (the contract's number);
+                   the workload is --tracks independent tracks per GPU, one 60 s segment of each per step
   value_pcie       the same K steps with pinned HOST buffers in and out: H2D audio + all kernels + D2H stems inside the
                    timed region (SURVEY 8(d)'s unit of work), transfers overlapped through the two pipeline slots
-  single_track     the --tracks 1 engine on the same GPU (one track at a time: the latency view)
+  value_single_segment         BASELINE config 3 as it is worded -- ONE track, its 60 s segments one after the other
+                   through the single-track engine (two segments in flight: the exact wavefront), HBM resident;
+  value_single_segment_pcie    ... the same with pinned host buffers; lone_segment_ms = one segment with nothing else in flight
+  checked_max_abs  after the timed region: two lanes of the batched engine, from a reset state, against the single-track
+                   engine on the same audio (max |difference| over the stems; `outputs_checked` = below 1e-5).  The
+                   oracle comparison of this configuration is tests/test_gpu_batch.py (full size, 32 and 48 lanes).
+  single_track     details of the --tracks 1 engine on the same GPU
   roofline         the dominant kernel by device time: live HIP-event duration per launch (events on the engine's own
-                   streams), algorithmic and issued flops per launch, roof, fraction; `traffic` = HBM bytes per launch
-                   from the rocprofv3 PMC summary named in `traffic_source` (2 x FETCH_SIZE + WRITE_SIZE, gfx950
-                   correction of MI355X_MICROARCH.md) -- read from that file at run time, null if it is absent
+                   streams); `achieved` / `frac` = ALGORITHMIC flops per launch / duration / peak of the
+                   pipe the kernel issues on; frac_issued = the same on issued matrix products; frac_latency for the
+                   recurrence; `traffic` = HBM bytes per launch from the rocprofv3 PMC summary named in `traffic_source`
+                   (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md), null if it is absent
   kernels          the same figures for every kernel family, so each fraction can be recomputed from the line
-  cpu_baseline     the oracle (reference flag set) on this box's host cores, bounded samples: config 3 on all cores
-                   (the headline leg) + `legs` for config 1 / config 3 on one thread and on all cores
+  cpu_baseline     the oracle (reference flag set, compiled on this box) on this box's host cores on the FULL 60 s segment:
+                   config 3 on all cores (the headline leg) + `legs` for config 1 / config 3 on one thread and on all cores
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank separates its own independent
 tracks (weak scaling; the path shards by track, no data-path collective); barrier + synchronize on both sides,
@@ -90,13 +98,15 @@ def cpu_leg(pkg, weights_path, seconds_audio, threads, flags, label):
 
 def cpu_baseline(pkg, weights_path, seconds_all, seconds_one):
     ncores = os.cpu_count()
+    built = ge.load_oracle().build_fast_native()  # -march=native of THIS box, not of the build container
     legs = [cpu_leg(pkg, weights_path, seconds_all, ncores, 0, "config 3: 4 stems + Wiener"),
             cpu_leg(pkg, weights_path, seconds_all, ncores, 0x700, "config 1: vocals model only (targets 0-2 skipped)"),
             cpu_leg(pkg, weights_path, seconds_one, 1, 0, "config 3: 4 stems + Wiener"),
             cpu_leg(pkg, weights_path, seconds_one, 1, 0x700, "config 1: vocals model only (targets 0-2 skipped)")]
     head = dict(legs[0])
-    head["sample"] += ("; Eigen-equivalent restatement (oracle/, -O3 -march=native -ffast-math -fopenmp, per-timestep GEMV LSTM, "
-                       "targets x directions threaded), not the Eigen binary")
+    head["sample"] += ("; Eigen-equivalent restatement (oracle/, -O3 -march=native -ffast-math -fopenmp, per-timestep GEMV LSTM), "
+                       "not the Eigen binary; library " + built + f"; {ncores} OpenMP threads of which the LSTM recurrence can use 8 "
+                       "(targets x directions -- the reference's own loop is serial there), the GEMMs all")
     head["legs"] = legs
     return head
 
@@ -131,8 +141,8 @@ def main():
     ap.add_argument("--safe-lstm", action="store_true", help="persistent LSTM kernel without the intra-XCD hand-off")
     ap.add_argument("--lstm-profile", action="store_true", help="print per-phase shader-clock counters of the LSTM kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=15.0, help="audio seconds of the all-cores CPU legs")
-    ap.add_argument("--cpu-sample-seconds-1t", type=float, default=1.5, help="audio seconds of the one-thread CPU legs")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=60.0, help="audio seconds of the all-cores CPU legs (60 = the full segment)")
+    ap.add_argument("--cpu-sample-seconds-1t", type=float, default=60.0, help="audio seconds of the one-thread CPU legs")
     ap.add_argument("--serial", action="store_true", help="sync after every step (no cross-segment pipelining)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the value_pcie leg")
     ap.add_argument("--no-single-track", action="store_true", help="skip the single-track (tracks = 1) leg")
@@ -245,6 +255,15 @@ def main():
             del h_in, h_out
         except Exception as e:  # noqa: BLE001 - reported, never a reason to lose the main number
             dt_pcie = repr(e)
+    # ---- value check of what was timed: two lanes from a reset state, compared below with the single-track
+    # engine on the same audio
+    check_lanes = sorted({0, B - 1})
+    check_stems = None
+    if rank == 0 and world == 1 and B > 1 and not args.no_single_track:
+        eng.track_stream_reset(-1)
+        eng.infer_batch_ptrs(aptrs, [N] * B, ptr_sets[0], flags)
+        eng.sync()
+        check_stems = {b: [out_sets[0][4 * b + t].cpu().numpy() for t in range(4)] for b in check_lanes}
     weight_bytes = eng.weight_bytes()
     if args.lstm_profile and rank == 0:
         for tag, pr in (("pipelined", prof_pipelined), ("alone", eng.lstm_profile())):
@@ -281,9 +300,44 @@ def main():
         step1()
         e1.sync()
         alone1 = e1.stage_times()
+        # one segment with nothing else in flight (sync after each)
+        lone = []
+        for _ in range(6):
+            t1 = time.perf_counter()
+            step1()
+            e1.sync()
+            lone.append((time.perf_counter() - t1) * 1e3)
+        # the same 16 back-to-back segments with pinned host buffers in and out
+        d1p = None
+        try:
+            h1 = torch.from_numpy(waves[0]).pin_memory()
+            ho1 = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4)] for _ in range(2)]
+            kp = [0]
+
+            def step1p():
+                e1.infer_batch_ptrs([h1.data_ptr()], [N], [o.data_ptr() for o in ho1[kp[0] & 1]], flags, where="host_async")
+                kp[0] += 1
+            d1p = mg.timed_region(step1p, fence1, 16, 4)
+        except Exception as e:  # noqa: BLE001
+            d1p = repr(e)
+        # value check: the batched engine's lanes against this engine, both from a reset state on the same audio
+        checked = None
+        if check_stems:
+            checked = 0.0
+            for b in check_lanes:
+                e1.stream_reset()
+                ab = torch.from_numpy(waves[b]).to(dev)
+                e1.infer_segment_device(ab.data_ptr(), N, p1[0], flags)
+                e1.sync()
+                for t in range(4):
+                    checked = max(checked, float(np.abs(o1[0][t].cpu().numpy() - check_stems[b][t]).max()))
         single = {"value": round(16 * (N / 44100.0) / d1, 2), "unit": "x realtime", "ms_per_step": round(d1 / 16 * 1e3, 3),
+                  "lone_segment_ms": round(float(np.median(lone)), 3),
+                  "value_pcie": round(16 * (N / 44100.0) / d1p, 2) if isinstance(d1p, float) else None,
+                  "ms_per_step_pcie": round(d1p / 16 * 1e3, 3) if isinstance(d1p, float) else d1p,
                   "tracks_per_gpu": 1, "lstm_kernel": "single-track (VALU, lstm_persistent_kernel)",
-                  "lstm_launch_ms": round(lstm1, 4), "lstm_launch_ms_alone": round(sum(alone1[f"lstm_rec{l}"] for l in range(3)) / 3, 4)}
+                  "lstm_launch_ms": round(lstm1, 4), "lstm_launch_ms_alone": round(sum(alone1[f"lstm_rec{l}"] for l in range(3)) / 3, 4),
+                  "checked_max_abs": checked, "checked_lanes": check_lanes if check_stems else None}
         e1.close()
 
     if rank == 0:
@@ -310,11 +364,14 @@ def main():
             alg = gemm[work_key] * (B if flavour == "planes" else 1)
             issued = alg * products if flavour != "f32" else alg
             peak = BF16_MFMA_PEAK_TF if flavour != "f32" else F32_MFMA_PEAK_TF
-            ach = issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            return {"kernel": name, "bound": "mfma", "launches_per_step": launches, "launch_ms": round(ms, 4),
-                    "launch_ms_alone": round(ms_alone, 4), "algorithmic_flops_per_launch": alg,
+            ach = alg / (ms * 1e-3) / 1e12 if ms > 0 else 0.0  # ALGORITHMIC flops / live launch duration
+            ach_issued = issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": name, "bound": "mfma", "pipe": "fp16 MFMA" if flavour != "f32" else "fp32 MFMA", "launches_per_step": launches,
+                    "launch_ms": round(ms, 4), "launch_ms_alone": round(ms_alone, 4), "algorithmic_flops_per_launch": alg,
                     "issued_flops_per_launch": issued, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "frac_alone": round(issued / (ms_alone * 1e-3) / 1e12 / peak, 4) if ms_alone > 0 else None,
+                    "frac": round(ach / peak, 4), "frac_issued": round(ach_issued / peak, 4),
+                    "frac_alone": round(alg / (ms_alone * 1e-3) / 1e12 / peak, 4) if ms_alone > 0 else None,
+                    "frac_issued_alone": round(issued / (ms_alone * 1e-3) / 1e12 / peak, 4) if ms_alone > 0 else None,
                     "algorithmic_TFLOPs_alone": round(alg / (ms_alone * 1e-3) / 1e12, 1) if ms_alone > 0 else None,
                     "traffic": find_traffic(*tneedles)}
         planes = flavour in ("planes", "bf16x3")  # both run on the bf16 matrix cores
@@ -342,17 +399,19 @@ def main():
             lstm_issued = lstm_alg
             lname = "lstm_persistent_kernel" if lstm_mode >= 1 else "lstm_step_kernel"
         lach = lstm_alg / (lms * 1e-3) / 1e12 if lms > 0 else 0.0
-        # the batched kernels run on the 16-bit matrix cores: priced on ISSUED products against that peak (like the GEMMs);
-        # the single-track kernel is fp32 VALU work: priced on algorithmic flops against the fp32 roof.  Either way the
-        # algorithmic rate against the fp32 roof is kept as `frac_of_fp32_roof_algorithmic` (round 1's figure: 0.097).
+        # `achieved` / `frac`: ALGORITHMIC flops per launch / live launch duration / peak of the pipe the kernel issues on
+        # (the batched kernels: fp16 matrix cores; the single-track kernel: fp32 VALU = the fp32 roof).  `frac_issued`
+        # prices the issued products (2 planes of h + the all-ones row-sum tile) the same way; the algorithmic rate
+        # against the fp32 roof stays as `frac_of_fp32_roof_algorithmic` (round 1's figure: 0.097).
         lpeak = BF16_MFMA_PEAK_TF if batched else F32_MFMA_PEAK_TF
-        lwork = lstm_issued if batched else lstm_alg
-        lrate = lwork / (lms * 1e-3) / 1e12 if lms > 0 else 0.0
-        kernels.append({"kernel": lname, "bound": "latency", "launches_per_step": 3, "launch_ms": round(lms, 4),
+        lrate_issued = lstm_issued / (lms * 1e-3) / 1e12 if lms > 0 else 0.0
+        kernels.append({"kernel": lname, "bound": "latency", "pipe": "fp16 MFMA" if batched else "fp32 VALU", "launches_per_step": 3,
+                        "launch_ms": round(lms, 4),
                         "launch_ms_alone": round(lms_alone, 4), "algorithmic_flops_per_launch": lstm_alg,
-                        "issued_flops_per_launch": lstm_issued, "achieved": round(lrate, 2), "peak": lpeak,
-                        "unit": "TFLOP/s", "frac": round(lrate / lpeak, 4),
-                        "frac_alone": round(lwork / (lms_alone * 1e-3) / 1e12 / lpeak, 4) if lms_alone > 0 else None,
+                        "issued_flops_per_launch": lstm_issued, "achieved": round(lach, 2), "peak": lpeak,
+                        "unit": "TFLOP/s", "frac": round(lach / lpeak, 4), "frac_issued": round(lrate_issued / lpeak, 4),
+                        "frac_alone": round(lstm_alg / (lms_alone * 1e-3) / 1e12 / lpeak, 4) if lms_alone > 0 else None,
+                        "frac_issued_alone": round(lstm_issued / (lms_alone * 1e-3) / 1e12 / lpeak, 4) if lms_alone > 0 else None,
                         "algorithmic_TFLOPs": round(lach, 2),
                         "frac_of_fp32_roof_algorithmic": round(lach / F32_MFMA_PEAK_TF, 4),
                         "frac_of_fp32_roof_algorithmic_alone": round(lstm_alg / (lms_alone * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, 4) if lms_alone > 0 else None,
@@ -387,13 +446,13 @@ def main():
         # dominant = the largest share of a step by stand-alone time (the in-pipeline spans of the small per-track kernels
         # include whatever the other slot ran beside them)
         dominant = max(kernels, key=lambda kk: (kk["launch_ms_alone"] or kk["launch_ms"]) * kk["launches_per_step"])
-        roofline = {kk: dominant.get(kk) for kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms",
+        roofline = {kk: dominant.get(kk) for kk in ("kernel", "bound", "pipe", "achieved", "peak", "unit", "frac", "frac_issued", "traffic", "launch_ms",
                                                     "launch_ms_alone", "launches_per_step", "algorithmic_flops_per_launch",
-                                                    "issued_flops_per_launch", "frac_alone", "algorithmic_TFLOPs", "frac_of_fp32_roof_algorithmic") if kk in dominant}
-        if roofline.get("bound") == "latency":  # the schema's enum is hbm | mfma; the batched recurrence runs on the matrix cores
-            roofline["bound_detail"] = "latency (serial recurrence)"
-            roofline["bound"] = "mfma"
-            roofline["frac_latency"] = dominant["frac_latency"]
+                                                    "issued_flops_per_launch", "frac_alone", "frac_issued_alone", "algorithmic_TFLOPs",
+                                                    "frac_of_fp32_roof_algorithmic", "frac_latency", "us_per_step", "us_per_step_alone") if kk in dominant}
+        if roofline.get("bound") == "latency":
+            roofline["bound_note"] = ("neither hbm nor mfma binds this kernel: 3*T serially dependent steps, each a chain-wide hand-off "
+                                      "(SURVEY 8d); `peak` is the peak of the pipe it issues on, `frac` what the algorithmic flops make of it")
         roofline["traffic_source"] = os.path.relpath(traffic_src, ROOT) if traffic_src and traffic else None
         roofline["share_of_device_time"] = round(dominant["launch_ms"] * dominant["launches_per_step"] /
                                                  max(sum(kk["launch_ms"] * kk["launches_per_step"] for kk in kernels), 1e-9), 3)
@@ -405,6 +464,11 @@ def main():
             "value": round(value, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_single_segment": single["value"] if single else None,
+            "value_single_segment_pcie": single["value_pcie"] if single else None,
+            "lone_segment_ms": single["lone_segment_ms"] if single else None,
+            "checked_max_abs": single["checked_max_abs"] if single else None,
+            "outputs_checked": (single["checked_max_abs"] is not None and single["checked_max_abs"] < 1e-5) if single else None,
             "value_pcie": (round(world * B * args.steps * seg_sec / dt_pcie, 2) if isinstance(dt_pcie, float) else None),
             "value_pcie_note": ("same steps with pinned host buffers: H2D audio + kernels + D2H stems inside the timed region, "
                                 f"{B * 2 * N * 4 * 5 / 1e6:.0f} MB over PCIe per step" if isinstance(dt_pcie, float) else dt_pcie),

@@ -110,7 +110,7 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 /* Track batching.  The reference is one track per process (umx.cpp:26-97) and its LSTM is one
  * matrix-vector product per step (lstm.cpp:132-161) -- on a GPU that step is bound by the cross-CU hand-off latency,
- * not by arithmetic.  A context created for n_tracks (1..16) independent tracks holds that many "track lanes", each
+ * not by arithmetic.  A context created for n_tracks (1..UMX_MAX_TRACKS = 48) independent tracks holds that many "track lanes", each
  * with its own streaming LSTM state (= its own std::array<lstm_data,4>, umx.cpp:167-171) and activation buffers;
  * umx_hip_infer_batch* runs one segment of every lane per call, and the recurrence of all lanes is ONE launch per
  * layer in which W_hh.h is a matrix-matrix product on the matrix cores (u8 W_hh as one exact fp16 plane against two fp16
@@ -149,7 +149,9 @@ int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, floa
                           unsigned flags);
 /* The same without the final wait: H2D, kernels and D2H are queued on the stream of the pipeline slot the segment
  * runs in (consecutive calls alternate between two slots).  With PINNED host buffers, and distinct buffers for two
- * consecutive calls, one segment's transfers overlap the other's kernels.  Results are valid after umx_hip_sync. */
+ * consecutive calls, one segment's transfers overlap the other's kernels.  Results are valid after umx_hip_sync.
+ * BUFFER CONTRACT: audio_host and out_host of every call queued since the last umx_hip_sync must stay valid and
+ * unchanged until that sync returns -- the timeout recovery described there uploads the audio again. */
 int umx_hip_infer_segment_async(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4],
                                 unsigned flags);
 /* Device-pointer form: buffers already in HBM (audio 2*n floats, out[t] 2*n floats each); asynchronous.
@@ -157,7 +159,9 @@ int umx_hip_infer_segment_async(umx_hip_ctx *ctx, const float *audio_host, int n
  * pipeline), so (1) audio_dev and out_dev must stay untouched by the caller until umx_hip_sync -- or until the
  * caller's stream has been ordered behind the engine with umx_hip_order_before; (2) two CONSECUTIVE calls must be
  * given DISTINCT out_dev buffers (both segments are in flight together); (3) work the caller queued on a stream
- * of its own that produces audio_dev is ordered in front of the next call with umx_hip_order_after. */
+ * of its own that produces audio_dev is ordered in front of the next call with umx_hip_order_after.
+ * A caller that fences with umx_hip_order_before (and then recycles its buffers) gives up the timeout recovery for the
+ * calls queued so far: a persistent-kernel timeout among them is reported as UMX_ERR_TIMEOUT by the next umx_hip_sync. */
 int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
                                  unsigned flags);
 /* One segment of each of n_tracks track lanes (lane i = the i-th track of the context, its LSTM state carries from
@@ -176,7 +180,9 @@ int umx_hip_infer_batch_device(umx_hip_ctx *ctx, int n_tracks, const float *cons
  * sync (a per-layer copy is kept for up to 8 queued calls), those segments are run again with the per-step driver
  * (bit-identical), and later calls of this context use that driver.  UMX_OK after a recovery; umx_hip_last_error then
  * starts with "recovered".  UMX_ERR_TIMEOUT (streaming state reset to zero) only when recovery is impossible: more
- * than 8 calls were queued, or the caller's device buffers of those calls are gone. */
+ * than 8 calls were queued since the last sync, or umx_hip_order_before released the caller's buffers of those calls.
+ * The stream-state entry points (umx_hip_[track_]stream_{reset,get,set}) synchronise through this function, so a
+ * sequence infer(A); stream_set; infer(B) replays A before the state is changed and B after it, never across it. */
 int umx_hip_sync(umx_hip_ctx *ctx);
 /* hip_stream = a hipStream_t of the caller.  order_after: everything queued by LATER calls on this context starts
  * only after what is on hip_stream now.  order_before: hip_stream waits for everything queued on the context so far. */
@@ -231,6 +237,24 @@ int umx_hip_segment_end(umx_hip_ctx *ctx, float *const out_host[4]);
  *   umx_hip_weight_stems_device    stems[t][k] *= transition weight of sample k (umx.cpp:197-206, 246), in place
  *   umx_hip_track_accumulate_device / _normalise_device   umx.cpp:234-273 on device buffers: track (2,length) x 4 +=
  *                                  already weighted stems at `offset`, sum_weight += weights; then track /= sum_weight */
+/* The back of a segment in two halves, for the driver that shards a track by SOURCE MODEL (host/mgpu.cpp, target mode):
+ * the per-target loop of umx_inference (inference.cpp:70-186) is independent per target until wiener_filter
+ * (inference.cpp:192-193), so a GPU runs begin / lstm_layer x 3 / masks with the other targets skipped
+ * (UMX_FLAG_SKIP_TARGET), the target magnitudes travel to the GPU that filters this segment, and that GPU finishes:
+ *   umx_hip_segment_masks_device   fc2, fc3, mask x |X| of the targets that are not skipped (after layer 2)
+ *   umx_hip_target_mag_device      device address of target t's magnitude [2][T][2049] of the phased segment (*floats = its
+ *                                  size): read it after _masks_device, or write a peer's result there before _finish_device
+ *   umx_hip_segment_finish_device  Wiener EM (or the mixture phase), inverse STFT, overlap-add from ALL four magnitude
+ *                                  buffers as they are (a skipped target is NOT zero-filled here) into 4 device buffers
+ * umx_hip_segment_end_device == _masks_device, zero-fill of the skipped targets, _finish_device. */
+int umx_hip_segment_masks_device(umx_hip_ctx *ctx);
+float *umx_hip_target_mag_device(umx_hip_ctx *ctx, int target, size_t *floats);
+int umx_hip_segment_finish_device(umx_hip_ctx *ctx, float *const out_dev[4]);
+int umx_hip_segment_discard(umx_hip_ctx *ctx); /* closes the phased segment where it stands (a rank that only contributes magnitudes) */
+/* Persistent LSTM launches of every context on `device` leave `cus` compute units out of their co-residency budget
+ * (the admission gate of umx_hip_sync's comment): room for kernels that are not this engine's and that may sit on a CU
+ * for a long time -- RCCL's send / recv kernels in host/mgpu.cpp.  Process-wide; 0 gives the budget back. */
+int umx_hip_gate_reserve(int device, int cus);
 void *umx_hip_phase_stream(umx_hip_ctx *ctx);
 float *umx_hip_stream_state_device(umx_hip_ctx *ctx);
 int umx_hip_segment_begin_device(umx_hip_ctx *ctx, const float *audio_dev, int n, unsigned flags);

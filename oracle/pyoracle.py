@@ -37,9 +37,30 @@ class Taps(C.Structure):
                 ("lstm_out", _fp * 4), ("mask", _fp * 4), ("target_mag", _fp * 4), ("y", _fp * 4), ("fc2_out", _fp * 4)]
 
 
+_fast_path = [None]  # set by build_fast_native(): the timed CPU baseline built for THIS machine's cores
+
+
+def build_fast_native():
+    """The reference's Release flag set (CMakeLists.txt:17-23: -O3 -march=native -ffast-math) compiled ON THE MACHINE THAT
+    TIMES IT, into oracle/_build/ (ignored by git and rebuilt per box): the prebuilt liboracle_fast.so travels from the
+    build container, whose -march=native is another CPU's.  Returns a description of what will be loaded; falls back to
+    the shipped library when there is no compiler.  Must run before the first lib(fast=True)."""
+    out = HERE / "_build" / "liboracle_fast_native.so"
+    try:
+        out.parent.mkdir(exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                               "-ffast-math", "-DNDEBUG", "-o", str(out), str(HERE / "umx_oracle.cpp"), "-lz"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        _fast_path[0] = out
+        _libs.pop(True, None)
+        return "built on this machine (-O3 -march=native -ffast-math -fopenmp)"
+    except Exception as e:  # noqa: BLE001 - the baseline is a report
+        return f"prebuilt in the build container (native build failed: {type(e).__name__})"
+
+
 def _load(fast=False):
     build()
-    lib = C.CDLL(str(HERE / ("liboracle_fast.so" if fast else "liboracle.so")))
+    lib = C.CDLL(str((_fast_path[0] or HERE / "liboracle_fast.so") if fast else HERE / "liboracle.so"))
     lib.oracle_tensor_name.restype = C.c_char_p
     lib.oracle_tensor_name.argtypes = [C.c_int]
     lib.oracle_tensor_numel.restype = C.c_size_t

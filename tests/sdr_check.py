@@ -1,4 +1,5 @@
-"""tests/sdr_check.py -- real-weight validation helper; test infrastructure, not collected by pytest.
+"""tests/sdr_check.py -- real-weight validation helper; test infrastructure; exercised by tests/test_gpu_sdr.py on synthetic
+UMX-L-shaped weights.
 
     python tests/sdr_check.py <ggml model (.bin or .bin.gz)> <mix.wav> [<dir with target_{0..3}.wav>] [--seconds S]
 
@@ -27,31 +28,46 @@ def sdr(ref, est):
     return 10 * np.log10(max(np.sum(ref ** 2), 1e-30) / max(np.sum((ref - est) ** 2), 1e-30))
 
 
+def run(model, wav, stems_dir=None, seconds=0.0, write_oracle_stems=None, out=print):
+    """-> {"engine_vs_oracle": [4 SDRs], "engine_vs_dir": [4 SDRs] or None}.  write_oracle_stems: a directory that receives
+    the oracle's stems as target_{0..3}.wav (the files the real umx.cpp binary would have written, umx.cpp:75-96)."""
+    pkg, po = ge.load_package(), ge.load_oracle()
+    wave, _channels = pkg.wav_load(wav)
+    if seconds > 0:
+        wave = wave[:, :int(seconds * 44100)]
+    N = pkg.SEGMENT_SAMPLES
+    eng = pkg.Engine.from_file(model, N)
+    got = eng.separate(wave, shift_offset=4033)
+    om = po.Model.load(model)
+    ref = po.shift_inference(om, wave, N, offset=4033)
+    if write_oracle_stems:
+        Path(write_oracle_stems).mkdir(parents=True, exist_ok=True)
+        for t in range(4):
+            pkg.wav_write(Path(write_oracle_stems) / f"target_{t}.wav", ref[t])
+    res = {"engine_vs_oracle": [], "engine_vs_dir": [] if stems_dir else None}
+    out(f"{wave.shape[1] / 44100:.1f} s, hidden {eng.hidden}; SDR in dB")
+    for t in range(4):
+        res["engine_vs_oracle"].append(sdr(ref[t], got[t]))
+        line = f"  target_{t} ({NAMES[t]:6s}) engine vs oracle {res['engine_vs_oracle'][-1]:7.2f}"
+        if stems_dir:
+            st, _ = pkg.wav_load(str(Path(stems_dir) / f"target_{t}.wav"))
+            n = min(st.shape[1], got[t].shape[1])
+            res["engine_vs_dir"].append(sdr(st[:, :n], got[t][:, :n]))
+            line += f"   engine vs {stems_dir}/target_{t}.wav {res['engine_vs_dir'][-1]:7.2f}"
+        out(line)
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("model")
     ap.add_argument("wav")
     ap.add_argument("stems_dir", nargs="?")
     ap.add_argument("--seconds", type=float, default=0.0, help="only the first S seconds (the oracle is slow)")
+    ap.add_argument("--write-oracle-stems", default=None, help="directory that receives the oracle's stems as wav files")
     a = ap.parse_args()
-    pkg, po = ge.load_package(), ge.load_oracle()
-    wave, _channels = pkg.wav_load(a.wav)
-    if a.seconds > 0:
-        wave = wave[:, :int(a.seconds * 44100)]
-    N = pkg.SEGMENT_SAMPLES
-    eng = pkg.Engine.from_file(a.model, N)
-    got = eng.separate(wave, shift_offset=4033)
-    om = po.Model.load(a.model)
-    ref = po.shift_inference(om, wave, N, offset=4033)
-    print(f"{wave.shape[1] / 44100:.1f} s, hidden {eng.hidden}; SDR in dB")
-    for t in range(4):
-        line = f"  target_{t} ({NAMES[t]:6s}) engine vs oracle {sdr(ref[t], got[t]):7.2f}"
-        if a.stems_dir:
-            st, _ = pkg.wav_load(str(Path(a.stems_dir) / f"target_{t}.wav"))
-            n = min(st.shape[1], got[t].shape[1])
-            line += f"   engine vs {a.stems_dir}/target_{t}.wav {sdr(st[:, :n], got[t][:, :n]):7.2f}"
-        print(line)
-    eng.close()
+    run(a.model, a.wav, a.stems_dir, a.seconds, a.write_oracle_stems)
 
 
 if __name__ == "__main__":

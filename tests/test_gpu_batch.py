@@ -167,6 +167,59 @@ def test_production_configuration_at_full_size_against_the_oracle(pkg, po, tmp_p
     eng.close()
 
 
+@pytest.mark.parametrize("B", [32, 48])
+def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path, B):
+    """what `bench.py` times by default -- 32 (and 48) track lanes x the full 60 s segment
+    (T = 2584) through lstm_batch2_kernel (groups of 16 lanes in turn: ring refills over 2,584 steps, 128-144 KB of LDS)
+    and plane-GEMM launches of 82,688 (124,032) rows -- against the ORACLE, not only `outputs_finite`.  Two distinct tracks
+    duplicated over the lanes: a lane of the first and a lane of the second group (0 and 17; 40 of the third for B = 48)
+    against the oracle on every stage tap, the stems and the carried state; every duplicate bitwise equal to its original;
+    and bitwise equal to the same track in a 3-lane context (one group: lstm_batch_kernel)."""
+    hidden, N = 1024, pkg.SEGMENT_SAMPLES
+    path = str(tmp_path / "m.bin.gz")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(hidden, seed=67), hidden)
+    om = po.Model.load(path)
+    tracks = [pkg.ggml.synth_audio(N, 410), pkg.ggml.synth_audio(N - 4321, 411)]
+    which = [(i * 7 + i // 16) % 2 for i in range(B)]  # both tracks in every group of 16 lanes
+    which[0], which[17] = 0, 1
+    checked = [0, 17] + ([40] if B > 32 else [])
+    eng = pkg.Engine.from_file(path, N, tracks=B)
+    assert eng.T == 2584 and eng.lstm_is_batched()
+    got = eng.infer_batch([tracks[which[i]] for i in range(B)], pkg.FLAG_DEBUG_TAPS)
+    assert eng.lstm_was_persistent()
+    refs = []
+    for k in range(2):
+        st = po.stream_state(hidden)
+        ref, taps = po.umx_inference(om, tracks[k], n_buf=N, state=st, want_taps=True)
+        refs.append((ref, taps, st))
+    for b in checked:
+        ref, taps, st = refs[which[b]]
+        for t in range(4):
+            for name, key, tol in (("fc1", "fc1_out", TOL_STAGE), ("lstm", "lstm_out", TOL_STAGE), ("fc2", "fc2_out", TOL_STAGE),
+                                   ("mask", "mask", TOL_STAGE), ("target_mag", "target_mag", TOL_STAGE), ("y", "y", 2e-4)):
+                err = rel_l2(eng.tap(f"{name}#{b}", t), taps[key][t])
+                assert err < tol, (B, b, t, name, err)
+            assert float(np.abs(got[b][t] - ref[t]).max()) < TOL_WAVE, (B, b, t)
+        assert rel_l2(eng.track_stream_get(b), st) < TOL_STAGE, (B, b)
+    first = {0: which.index(0), 1: which.index(1)}
+    states = {k: eng.track_stream_get(first[k]) for k in (0, 1)}
+    for b in range(B):
+        k = which[b]
+        assert (eng.track_stream_get(b) == states[k]).all(), (B, b)
+        for t in range(4):
+            assert (got[b][t] == got[first[k]][t]).all(), (B, b, t)
+    keep = {k: ([got[first[k]][t].copy() for t in range(4)], states[k]) for k in (0, 1)}
+    del got
+    eng.close()
+    small = pkg.Engine.from_file(path, N, tracks=3)
+    g3 = small.infer_batch([tracks[1], tracks[0], tracks[1]])
+    for lane, k in ((0, 1), (1, 0), (2, 1)):
+        assert (small.track_stream_get(lane) == keep[k][1]).all(), (B, lane)
+        for t in range(4):
+            assert (g3[lane][t] == keep[k][0][t]).all(), (B, lane, t)
+    small.close()
+
+
 def test_batched_kernel_agrees_with_single_track_kernel(pkg, tmp_path):
     """Same track through the single-track (VALU) kernel and the batched (matrix-core) kernel: different summation
     order, so not bitwise -- but far inside the parity tolerance."""

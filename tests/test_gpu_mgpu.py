@@ -1,8 +1,11 @@
 """The C++17 multi-GPU track driver (include/umx_mgpu.h, host/mgpu.cpp): BASELINE config 4.  On the one-GPU test box:
-world 1 through the device-resident path (same kernels, no communicator) must equal the single-GPU whole-track driver
-bit for bit; world 2 with both ranks on the one device exercises the RCCL send / recv path where the RCCL build
-accepts two ranks per device (otherwise the reason is reported and the test is skipped -- the driver's 8-GPU run is
-the one that times it)."""
+  * world 1 through the device-resident path (same kernels, no communicator) must equal the single-GPU whole-track
+    driver bit for bit;
+  * world 1 LOOPBACK: a one-rank RCCL communicator, every LSTM-state hop, every target-magnitude exchange and every stem
+    gather through a grouped RCCL self send + receive on the streams a real run uses, the outgoing buffers poisoned in
+    between -- the RCCL path executes on one GPU, segment-sharded and target-sharded, bitwise equal to the one-GPU driver;
+    a persistent-LSTM timeout inside it is found through the status all-reduce and the track retried;
+  * world 2 / 3 with all ranks on the one device where the RCCL build accepts that (otherwise skipped with the reason)."""
 import subprocess
 import sys
 from pathlib import Path
@@ -27,6 +30,44 @@ def test_world1_device_path_equals_whole_track_driver(pkg, tmp_path):
         for t in range(4):
             assert (got[t] == ref[t]).all(), (L, off, t)
     mg.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("by_target", [False, True], ids=["segments", "targets"])
+def test_rccl_loopback_executes_every_hop_and_equals_the_one_gpu_driver(pkg, tmp_path, by_target):
+    H, N = 1024, 24 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=73), H, compress=False)
+    eng = pkg.Engine.from_file(path, N)
+    mg = pkg.MultiGpuTrack(eng, loopback=True, by_target=by_target)
+    for L, off, flags in ((int(N * 3.3), 4033, 0), (int(N * 2.1), None, pkg.FLAG_NO_WIENER), (int(N * 1.6), 20000, 0x700)):
+        wave = pkg.ggml.synth_audio(L, 820 + L % 7)
+        ref = eng.separate(wave, flags=flags, shift_offset=off)
+        got = mg.separate(wave, shift_offset=off, flags=flags)
+        st = mg.stats()
+        nseg = len(pkg.segment_plan(L + (0 if off is None else max(22050 - off, off)), N)[0])
+        assert st["state_hops"] == 2 * 4 * 3 * (nseg - 1) and st["stem_transfers"] == 4 * nseg and st["magnitude_transfers"] == 8 * nseg
+        assert st["retries"] == 0
+        for t in range(4):
+            assert np.isfinite(got[t]).all()
+            assert (got[t] == ref[t]).all(), (L, off, t)
+    # a persistent launch that gives up half way (as if another process held the CUs): every rank learns it from the
+    # status all-reduce, nothing is handed out, the track is run again (this rank on the per-step driver): same bits
+    wave = pkg.ggml.synth_audio(int(N * 2.4), 830)
+    ref = eng.separate(wave, shift_offset=4033)
+    got = mg.separate(wave, shift_offset=4033, flags=pkg.FLAG_DEBUG_LSTM_ABORT)
+    assert mg.stats()["retries"] == 1
+    for t in range(4):
+        assert (got[t] == ref[t]).all(), t
+    mg.close()
+    eng.close()
+
+
+def test_mgpu_refuses_a_track_batched_context(pkg, model_small):
+    path, om, targets = model_small
+    eng = pkg.Engine(targets, 128, 16 * 1024, tracks=2)
+    with pytest.raises(pkg.UmxError):
+        pkg.MultiGpuTrack(eng)
     eng.close()
 
 

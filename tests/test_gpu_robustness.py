@@ -117,3 +117,95 @@ def test_whole_track_is_retried_after_a_timeout(pkg, model_small):
     for t in range(4):
         assert (got[t] == ref[t]).all()
     eng.close()
+
+
+def _host_async(pkg, eng, waves, flags_first=0):
+    """Queue every wave through the host-pointer async form (pinned buffers), one sync at the end."""
+    import torch
+    N = waves[0].shape[1]
+    ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).pin_memory() for w in waves]
+    outs = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4)] for _ in waves]
+    for i in range(len(waves)):
+        eng.infer_batch_ptrs([ins[i].data_ptr()], [N], [o.data_ptr() for o in outs[i]], flags_first if i == 0 else 0, where="host_async")
+    eng.sync()
+    return [[o.numpy().copy() for o in seg] for seg in outs], eng.stream_get()
+
+
+def test_recovery_replays_many_queued_host_calls_on_their_own_audio(pkg, umxl):
+    """the host-pointer async form stages audio in two internal buffers; with 5 calls queued before one
+    sync, call k's staged audio has been overwritten by call k + 2 when the replay starts.  The replay must upload every
+    call's own audio again: same stems and state as an undisturbed run."""
+    import torch
+    torch.zeros(1).cuda()
+    N, NSEG = 24 * 1024, 5
+    waves = [pkg.ggml.synth_audio(N, 340 + i) for i in range(NSEG)]
+    eng = pkg.Engine.from_file(umxl, N)
+    ref, ref_state = _host_async(pkg, eng, waves)
+    eng.stream_reset()
+    got, state = _host_async(pkg, eng, waves, pkg.FLAG_DEBUG_LSTM_ABORT)
+    assert eng.last_error().startswith("recovered")
+    assert (state == ref_state).all()
+    for i in range(NSEG):
+        for t in range(4):
+            assert (got[i][t] == ref[i][t]).all(), (i, t)
+    eng.close()
+
+
+def test_state_change_between_queued_calls_is_not_replayed_across(pkg, umxl):
+    """infer(A, times out); stream_set(S); infer(B); sync: A is repaired before S is applied, B starts from S."""
+    import torch
+    torch.zeros(1).cuda()
+    N = 24 * 1024
+    a, b = pkg.ggml.synth_audio(N, 350), pkg.ggml.synth_audio(N, 351)
+    eng = pkg.Engine.from_file(umxl, N)
+    ref_a = eng.infer_segment(a)
+    S = eng.stream_get()
+    eng.stream_set(0.5 * S)
+    ref_b = eng.infer_segment(b)
+    ref_state = eng.stream_get()
+    eng.stream_reset()
+    (got_a,), _ = _host_async(pkg, eng, [a], pkg.FLAG_DEBUG_LSTM_ABORT)  # sync inside: recovered here
+    ina = torch.from_numpy(np.ascontiguousarray(a.T).ravel()).cuda()
+    outs = [torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)]
+    eng2 = pkg.Engine.from_file(umxl, N)
+    eng2.infer_segment_device(ina.data_ptr(), N, [o.data_ptr() for o in outs], pkg.FLAG_DEBUG_LSTM_ABORT)  # queued, times out
+    eng2.stream_set(0.5 * S)  # synchronises through umx_hip_sync: A replayed first, then the state is replaced
+    assert eng2.last_error().startswith("recovered")
+    for t in range(4):
+        assert (outs[t].cpu().numpy() == np.ascontiguousarray(ref_a[t].T).ravel()).all()
+    got_b = eng2.infer_segment(b)
+    assert (eng2.stream_get() == ref_state).all()
+    for t in range(4):
+        assert (got_b[t] == ref_b[t]).all()
+        assert (got_a[t] == np.ascontiguousarray(ref_a[t].T).ravel()).all()
+    eng.close()
+    eng2.close()
+
+
+def test_order_before_gives_up_recovery_and_bounds_the_log(pkg, umxl):
+    """A caller that fences with umx_hip_order_before may recycle its buffers: the calls queued so far cannot be replayed,
+    so a timeout among them must surface as UMX_ERR_TIMEOUT (not a silent 'recovered' on recycled data)."""
+    import torch
+    torch.zeros(1).cuda()
+    N = 24 * 1024
+    w = pkg.ggml.synth_audio(N, 360)
+    eng = pkg.Engine.from_file(umxl, N)
+    ina = torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda()
+    outs = [torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)]
+    eng.infer_segment_device(ina.data_ptr(), N, [o.data_ptr() for o in outs], pkg.FLAG_DEBUG_LSTM_ABORT)
+    assert eng.lib.umx_hip_order_before(eng.h, torch.cuda.current_stream().cuda_stream) == 0
+    with pytest.raises(pkg.UmxError) as ei:
+        eng.sync()
+    assert ei.value.code == pkg.ERR_TIMEOUT
+    assert np.abs(eng.stream_get()).max() == 0  # documented: state reset to zero
+    eng.close()
+    # more than 8 calls between syncs: same outcome, and the context keeps working afterwards (per-step driver)
+    eng = pkg.Engine.from_file(umxl, N)
+    for i in range(10):
+        eng.infer_segment_device(ina.data_ptr(), N, [o.data_ptr() for o in outs], pkg.FLAG_DEBUG_LSTM_ABORT if i == 9 else 0)
+    with pytest.raises(pkg.UmxError) as ei:
+        eng.sync()
+    assert ei.value.code == pkg.ERR_TIMEOUT
+    got = eng.infer_segment(w)
+    assert eng.lstm_mode() == 0 and all(np.isfinite(g).all() for g in got)
+    eng.close()

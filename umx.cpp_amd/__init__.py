@@ -156,7 +156,8 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
-               "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits"]
+               "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits",
+               "umx_hip_segment_masks_device", "umx_hip_target_mag_device", "umx_hip_segment_finish_device", "umx_hip_gate_reserve", "umx_hip_segment_discard"]
 
 
 def views_from_file_tensors(targets, quantised=True):
@@ -665,8 +666,9 @@ def engine_backend(eng, flags=0):
 
 
 # ------------------------------------------------------------------ multi-GPU track driver (umx_mgpu.h)
-MGPU_SYMBOLS = ["umx_mgpu_unique_id", "umx_mgpu_create", "umx_mgpu_destroy", "umx_mgpu_separate_track"]
-MGPU_ID_BYTES = 256
+MGPU_SYMBOLS = ["umx_mgpu_unique_id", "umx_mgpu_create", "umx_mgpu_create_ex", "umx_mgpu_destroy", "umx_mgpu_separate_track", "umx_mgpu_stats"]
+MGPU_ID_BYTES = 640
+MGPU_BY_TARGET, MGPU_LOOPBACK = 0x1, 0x2
 _mgpu = None
 
 
@@ -682,8 +684,10 @@ def mgpu_lib():
     lib = C.CDLL(str(path))
     lib.umx_mgpu_unique_id.argtypes = [C.c_char_p, C.c_char_p]
     lib.umx_mgpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    lib.umx_mgpu_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_uint, C.c_char_p]
     lib.umx_mgpu_destroy.argtypes = [C.c_void_p]
     lib.umx_mgpu_separate_track.argtypes = [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(_fp), C.c_uint, C.c_char_p]
+    lib.umx_mgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     _mgpu = lib
     return lib
 
@@ -698,15 +702,17 @@ def mgpu_unique_id():
 
 
 class MultiGpuTrack:
-    """One track over `world` GPUs, exact (include/umx_mgpu.h): rank s % world runs segment s, LSTM layer states and
-    weighted stems travel over RCCL point to point on device pointers.  ids: the bytes of mgpu_unique_id() made on
-    rank 0 and handed to every rank (None when world == 1)."""
+    """One track over `world` GPUs, exact (include/umx_mgpu.h): world = G target groups x P segment-pipeline stages; LSTM
+    layer states, target magnitudes and weighted stems travel over RCCL point to point on device pointers.  ids: the
+    bytes of mgpu_unique_id() made on rank 0 and handed to every rank (None when world == 1).  by_target: shard by source
+    model as well (G = gcd(world, 4)); loopback (world 1 only): every transfer through a grouped RCCL self send + receive."""
 
-    def __init__(self, engine, rank=0, world=1, ids=None):
+    def __init__(self, engine, rank=0, world=1, ids=None, by_target=False, loopback=False):
         self.lib, self.eng, self.rank = mgpu_lib(), engine, rank
         h = C.c_void_p()
         err = C.create_string_buffer(256)
-        rc = self.lib.umx_mgpu_create(C.byref(h), engine.h, rank, world, ids, err)
+        rc = self.lib.umx_mgpu_create_ex(C.byref(h), engine.h, rank, world, ids, (MGPU_BY_TARGET if by_target else 0) |
+                                         (MGPU_LOOPBACK if loopback else 0), err)
         if rc:
             raise UmxError(rc, err.value.decode())
         self.h = h
@@ -724,6 +730,12 @@ class MultiGpuTrack:
         if rc:
             raise UmxError(rc, err.value.decode())
         return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs] if outs else None
+
+    def stats(self):
+        """{rccl_ops, state_hops, magnitude_transfers, stem_transfers, retries} of the last track."""
+        buf = (C.c_longlong * 5)()
+        self.lib.umx_mgpu_stats(self.h, buf)
+        return dict(zip(("rccl_ops", "state_hops", "magnitude_transfers", "stem_transfers", "retries"), [int(x) for x in buf]))
 
     def close(self):
         if getattr(self, "h", None):

@@ -145,6 +145,7 @@ struct LstmGate
     };
     std::vector<Grid> inflight;
     std::vector<hipEvent_t> pool;
+    int reserved = 0; // half CUs kept free for kernels that are not this engine's (RCCL send / recv: umx_hip_gate_reserve)
 };
 LstmGate g_gate[16];
 
@@ -153,6 +154,7 @@ template <class Launch> hipError_t lstm_gate_launch(int device, hipStream_t st, 
 {
     LstmGate &g = g_gate[device & 15];
     std::lock_guard<std::mutex> lock(g.m);
+    capacity_units -= g.reserved;
     int used = 0;
     for (size_t i = 0; i < g.inflight.size();)
         if (hipEventQuery(g.inflight[i].done) == hipSuccess)
@@ -272,10 +274,14 @@ struct umx_hip_ctx
         int n[LSTMB_MAX_TRACKS];
         float *out[4 * LSTMB_MAX_TRACKS];
         float *host_out[4 * LSTMB_MAX_TRACKS]; // host-pointer entry points: where the stems are copied afterwards
+        const float *host_audio[LSTMB_MAX_TRACKS]; // ... and where the audio came from: the two staging buffers have been
+                                                   // reused by later calls, so a replay uploads it again
         unsigned flags;
     };
     static constexpr int kBackupCalls = 8;
-    std::vector<PendingCall> pending;
+    std::vector<PendingCall> pending; // at most kBackupCalls entries
+    bool pending_lost = false;        // calls were queued that cannot be replayed: more than kBackupCalls since the last sync,
+                                      // or the caller was released from the buffer contract (umx_hip_order_before)
     float *backup = nullptr; // [kBackupCalls][3 layers][B * state_floats]: the stream state right before each layer launch
     bool no_recovery = false, recovering = false;
     int recover();
@@ -356,6 +362,14 @@ struct umx_hip_ctx
     int stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active, int nact);
     int stage_back(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n,
                    unsigned flags, const int *active, int nact);
+    // its two halves: fc2 + fc3 -> the target magnitudes of the active targets | Wiener (or mixture phase), inverse STFT,
+    // overlap-add from the magnitudes of ALL four targets (zero_skipped: a skipped target counts as silence; false when
+    // its magnitudes were put there by someone else -- the target-sharded multi-GPU driver)
+    int stage_masks(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, unsigned flags, const int *active, int nact);
+    int stage_finish(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n, unsigned flags,
+                     bool zero_skipped);
+    int phase_masks();
+    int phase_finish_device(float *const out_dev_[4]);
     static void active_list(unsigned flags, int *active, int &nact)
     {
         nact = 0;
@@ -402,7 +416,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
 {
     if (n_tracks < 1 || n_tracks > LSTMB_MAX_TRACKS)
     {
-        set_error("n_tracks must be in [1, 16]");
+        set_error("n_tracks must be in [1, 48]");
         return UMX_ERR_ARG;
     }
     B = n_tracks;
@@ -1636,16 +1650,32 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
 int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n,
                             unsigned flags, const int *active, int nact)
 {
+    if (int rc = stage_masks(sl, st, nb, audio_dev, flags, active, nact))
+        return rc;
+    return stage_finish(sl, st, nb, audio_dev, out, n, flags, true);
+}
+
+int umx_hip_ctx::stage_masks(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, unsigned flags, const int *active, int nact)
+{
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC2, 0, active, nact, dbg);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC3, 0, active, nact, dbg);
-    for (int ln = 0; ln < nb; ++ln)
-        if (audio_dev[ln])
-            for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
-                if (flags & UMX_FLAG_SKIP_TARGET(tg))
-                    UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
+    UMX_HIP_CHECK(hipGetLastError());
+    return UMX_OK;
+}
+
+int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n,
+                              unsigned flags, bool zero_skipped)
+{
+    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
+    if (zero_skipped)
+        for (int ln = 0; ln < nb; ++ln)
+            if (audio_dev[ln])
+                for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
+                    if (flags & UMX_FLAG_SKIP_TARGET(tg))
+                        UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_WIENER], st));
     const int bt = (NBINS + 255) / 256;
     for (int ln = 0; ln < nb; ++ln)
@@ -1797,7 +1827,13 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
                     sl.lane[ln].ta[tg].mask_dbg = all + (size_t)ln * T * NOUT;
             }
     last_flags = flags;
-    const size_t call_idx = pending.size();
+    const size_t call_idx = pending_lost ? (size_t)kBackupCalls : pending.size();
+    if (call_idx >= (size_t)kBackupCalls)
+    {
+        pending_lost = true; // no state backup left for this call: a timeout before the next sync cannot be repaired
+        pending.clear();
+    }
+    else
     {
         PendingCall pc;
         memset(&pc, 0, sizeof pc);
@@ -1874,6 +1910,7 @@ int umx_hip_ctx::tracks(int nt, const float *const *audio_host, const int *lengt
         rc = tracks_once(nt, audio_host, length, shift_offset, out_host, flags, progress, progress_user);
     no_recovery = false;
     pending.clear();
+    pending_lost = false;
     return rc;
 }
 
@@ -2153,6 +2190,44 @@ int umx_hip_ctx::phase_end_device(float *const out_dev_[4])
     return UMX_OK;
 }
 
+// fc2 + fc3 of the active targets: their magnitudes are in HBM afterwards (umx_hip_target_mag_device)
+int umx_hip_ctx::phase_masks()
+{
+    if (ph_next != 3)
+    {
+        set_error("segment_masks: all three LSTM layers must have run");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    Slot &sl = slot[0];
+    int active[4], nact;
+    active_list(ph_flags, active, nact);
+    const float *ain = ph_audio ? ph_audio : audio_in;
+    if (int rc = stage_masks(sl, sl.stream, 1, &ain, ph_flags, active, nact))
+        return rc;
+    ph_next = 4;
+    return UMX_OK;
+}
+
+// Wiener + inverse STFT from the magnitudes of all four targets, wherever they came from
+int umx_hip_ctx::phase_finish_device(float *const out_dev_[4])
+{
+    if (ph_next != 4 || !out_dev_)
+    {
+        set_error("segment_finish: umx_hip_segment_masks_device must have run");
+        return UMX_ERR_ARG;
+    }
+    UMX_HIP_CHECK(hipSetDevice(device));
+    Slot &sl = slot[0];
+    ph_next = -1;
+    const float *ain = ph_audio ? ph_audio : audio_in;
+    if (int rc = stage_finish(sl, sl.stream, 1, &ain, out_dev_, &ph_n, ph_flags, false))
+        return rc;
+    cur = 0;
+    slot[0].used = slot[1].used = false;
+    return UMX_OK;
+}
+
 int umx_hip_ctx::phase_layer(int layer)
 {
     if (ph_next < 0 || ph_next > 2 || layer != ph_next)
@@ -2249,6 +2324,13 @@ int umx_hip_ctx::recover()
     int rc = UMX_OK;
     for (const PendingCall &pc : calls)
     {
+        // host-pointer form: the staging buffer this call read has since been overwritten by the call two later (two
+        // staging buffers, up to kBackupCalls calls queued) -- upload the caller's audio again, on the stream the replay of
+        // this call is about to be queued on (the earlier user of the buffer ran on the same stream or has been waited for)
+        for (int ln = 0; ln < pc.nb; ++ln)
+            if (pc.host_audio[ln] && pc.audio[ln])
+                UMX_HIP_CHECK(hipMemcpyAsync(const_cast<float *>(pc.audio[ln]), pc.host_audio[ln], sizeof(float) * 2 * (size_t)pc.n[ln],
+                                             hipMemcpyHostToDevice, slot[nseg & 1].stream));
         if ((rc = infer_batch(pc.nb, pc.audio, pc.n, pc.out, (pc.flags | UMX_FLAG_LSTM_STEPWISE) & ~UMX_FLAG_DEBUG_LSTM_ABORT)) != UMX_OK)
             break;
         for (int k = 0; k < 4 * pc.nb; ++k) // the host-pointer forms had copied the failed run's stems out
@@ -2260,6 +2342,7 @@ int umx_hip_ctx::recover()
     if (rc == UMX_OK)
         rc = sync_all();
     pending.clear();
+    pending_lost = false;
     return rc;
 }
 
@@ -2363,7 +2446,9 @@ int umx_hip_track_stream_reset(umx_hip_ctx *ctx, int track)
 {
     if (!ctx || track >= ctx->B)
         return UMX_ERR_ARG;
-    if (int rc = ctx->sync_all())
+    // through umx_hip_sync, not a bare stream wait: a timed-out launch among the calls queued so far is noticed (and
+    // repaired by replaying them) BEFORE the state is changed, and the replay log starts afresh behind the change
+    if (int rc = umx_hip_sync(ctx))
         return rc;
     const size_t per = ctx->state_floats();
     hipError_t e = track < 0 ? hipMemset(ctx->state, 0, sizeof(float) * per * ctx->B)
@@ -2382,7 +2467,7 @@ int umx_hip_track_stream_get(umx_hip_ctx *ctx, int track, float *host_dst)
 {
     if (!ctx || !host_dst || track < 0 || track >= ctx->B)
         return UMX_ERR_ARG;
-    if (int rc = ctx->sync_all())
+    if (int rc = umx_hip_sync(ctx))
         return rc;
     const size_t per = ctx->state_floats();
     hipError_t e = hipMemcpy(host_dst, ctx->state + per * track, sizeof(float) * per, hipMemcpyDeviceToHost);
@@ -2399,7 +2484,7 @@ int umx_hip_track_stream_set(umx_hip_ctx *ctx, int track, const float *host_src)
 {
     if (!ctx || !host_src || track < 0 || track >= ctx->B)
         return UMX_ERR_ARG;
-    if (int rc = ctx->sync_all())
+    if (int rc = umx_hip_sync(ctx))
         return rc;
     const size_t per = ctx->state_floats();
     hipError_t e = hipMemcpy(ctx->state + per * track, host_src, sizeof(float) * per, hipMemcpyHostToDevice);
@@ -2503,6 +2588,34 @@ int umx_hip_segment_begin_device(umx_hip_ctx *ctx, const float *audio_dev, int n
     return ctx ? ctx->phase_begin_device(audio_dev, n, flags) : UMX_ERR_ARG;
 }
 int umx_hip_segment_end_device(umx_hip_ctx *ctx, float *const out_dev[4]) { return ctx ? ctx->phase_end_device(out_dev) : UMX_ERR_ARG; }
+int umx_hip_segment_masks_device(umx_hip_ctx *ctx) { return ctx ? ctx->phase_masks() : UMX_ERR_ARG; }
+int umx_hip_segment_discard(umx_hip_ctx *ctx)
+{
+    if (!ctx)
+        return UMX_ERR_ARG;
+    ctx->ph_next = -1; // whatever was queued runs to its end; the next segment may begin
+    ctx->cur = 0;
+    ctx->slot[0].used = ctx->slot[1].used = false;
+    return UMX_OK;
+}
+int umx_hip_segment_finish_device(umx_hip_ctx *ctx, float *const out_dev[4]) { return ctx ? ctx->phase_finish_device(out_dev) : UMX_ERR_ARG; }
+float *umx_hip_target_mag_device(umx_hip_ctx *ctx, int target, size_t *floats)
+{
+    if (!ctx || target < 0 || target > 3)
+        return nullptr;
+    if (floats)
+        *floats = (size_t)2 * ctx->T * NBINS;
+    return ctx->slot[0].lane[0].ta[target].mag;
+}
+int umx_hip_gate_reserve(int device, int cus)
+{
+    if (device < 0 || cus < 0)
+        return UMX_ERR_ARG;
+    LstmGate &g = g_gate[device & 15];
+    std::lock_guard<std::mutex> lock(g.m);
+    g.reserved = 2 * cus;
+    return UMX_OK;
+}
 
 static Stems4 stems4(float *const p[4])
 {
@@ -2578,6 +2691,14 @@ int umx_hip_order_before(umx_hip_ctx *ctx, void *hip_stream)
 {
     if (!ctx)
         return UMX_ERR_ARG;
+    // the caller may recycle the buffers of the calls queued so far once its stream is ordered behind them: they can no
+    // longer be replayed, so a timeout among them ends as UMX_ERR_TIMEOUT at the next umx_hip_sync (and the log of
+    // queued calls stops growing for callers that never call umx_hip_sync)
+    if (!ctx->pending.empty())
+    {
+        ctx->pending_lost = true;
+        ctx->pending.clear();
+    }
     hipError_t e = hipSuccess;
     if (!ctx->order_ev)
         e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming);
@@ -2622,7 +2743,7 @@ int umx_hip_sync(umx_hip_ctx *ctx)
                 (void)hipMemset(ctx->slot[sj].status, 0, sizeof(unsigned));
             ctx->persistent_ok = false; // later launches use the per-step driver
             const size_t ncalls = ctx->pending.size();
-            if (!ctx->no_recovery && ncalls >= 1 && ncalls <= (size_t)umx_hip_ctx::kBackupCalls)
+            if (!ctx->no_recovery && !ctx->pending_lost && ncalls >= 1 && ncalls <= (size_t)umx_hip_ctx::kBackupCalls)
             {
                 const int rc = ctx->recover();
                 if (rc == UMX_OK)
@@ -2636,11 +2757,13 @@ int umx_hip_sync(umx_hip_ctx *ctx)
             (void)hipMemset(ctx->state, 0, sizeof(float) * ctx->state_floats() * ctx->B);
             ctx->slot[0].used = ctx->slot[1].used = false;
             ctx->pending.clear();
+            ctx->pending_lost = false;
             ctx->set_error(what + "; the streaming LSTM state was reset to zero, later segments run the per-step driver");
             return UMX_ERR_TIMEOUT;
         }
     }
     ctx->pending.clear();
+    ctx->pending_lost = false;
     return UMX_OK;
 }
 
@@ -2680,8 +2803,13 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
     }
     if (int rc = ctx->infer_batch(n_tracks, ain, n, ctx->stage_out[si], flags))
         return rc;
-    for (int k = 0; k < 4 * n_tracks; ++k)
-        ctx->pending.back().host_out[k] = out_host[k];
+    if (!ctx->pending_lost && !ctx->pending.empty())
+    {
+        for (int k = 0; k < 4 * n_tracks; ++k)
+            ctx->pending.back().host_out[k] = out_host[k];
+        for (int ln = 0; ln < n_tracks; ++ln)
+            ctx->pending.back().host_audio[ln] = ain[ln] ? audio_host[ln] : nullptr;
+    }
     for (int ln = 0; ln < n_tracks; ++ln)
         if (ain[ln])
             for (int s = 0; s < 4; ++s)

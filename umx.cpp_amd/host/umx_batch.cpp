@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <filesystem>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -53,11 +54,16 @@ int main(int argc, const char **argv)
     umx_model_free(model);
     const unsigned flags = env_int("UMX_NO_WIENER", 0) ? UMX_FLAG_NO_WIENER : 0;
     double audio_secs = 0, wall = 0;
+    const int first_rand_shift = rand() % UMX_MAX_SHIFT; // glibc, unseeded: 4033
+    std::set<std::string> used_names; // output directories are named after the file's stem: a/x.wav and b/x.wav must not collide
     for (int f0 = 0; f0 < nfiles; f0 += lanes)
     {
         const int nb = std::min(lanes, nfiles - f0);
         std::vector<float *> audio(nb, nullptr);
-        std::vector<int> n(nb, 0), shift(nb, env_int("UMX_SHIFT_OFFSET", -1) < 0 ? rand() % UMX_MAX_SHIFT : env_int("UMX_SHIFT_OFFSET", -1));
+        // umx.cpp:115 draws rand() % 22050 once per PROCESS, and the reference never seeds rand(): every run of its CLI
+        // shifts by the same 4033 samples.  Every file here gets that value too (not a fresh draw per batch of lanes),
+        // so a file's stems do not depend on where in the argument list it stands; UMX_SHIFT_OFFSET overrides it.
+        std::vector<int> n(nb, 0), shift(nb, env_int("UMX_SHIFT_OFFSET", -1) < 0 ? first_rand_shift : env_int("UMX_SHIFT_OFFSET", -1));
         std::vector<std::vector<float>> stems(4 * nb);
         std::vector<float *> out(4 * nb);
         std::vector<const float *> in(nb);
@@ -86,7 +92,10 @@ int main(int argc, const char **argv)
         wall += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (int i = 0; i < nb; ++i)
         {
-            const std::filesystem::path dir = std::filesystem::path(out_dir) / std::filesystem::path(argv[3 + f0 + i]).stem();
+            std::string name = std::filesystem::path(argv[3 + f0 + i]).stem().string();
+            for (int k = 2; !used_names.insert(name).second; ++k)
+                name = std::filesystem::path(argv[3 + f0 + i]).stem().string() + "_" + std::to_string(k);
+            const std::filesystem::path dir = std::filesystem::path(out_dir) / name;
             std::error_code ec;
             std::filesystem::create_directories(dir, ec);
             for (int t = 0; t < 4; ++t) // umx.cpp:75-96
