@@ -35,6 +35,18 @@
 
 using namespace umx;
 
+// UMX_HIP_CHECK for the free functions of the C-ABI (the error goes to the context)
+#define UMX_HIP_CHECK_CTX(ctx_, expr)                                                                                \
+    do                                                                                                               \
+    {                                                                                                                \
+        hipError_t _e = (expr);                                                                                      \
+        if (_e != hipSuccess)                                                                                        \
+        {                                                                                                            \
+            (ctx_)->set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                                    \
+            return UMX_ERR_HIP;                                                                                      \
+        }                                                                                                            \
+    } while (0)
+
 namespace
 {
 std::string g_create_error = "";
@@ -123,6 +135,11 @@ struct Slot
     unsigned long long *lprof = nullptr;
     hipEvent_t ev[ST_COUNT + 1] = {};
     hipEvent_t rec_done[3] = {}; // LSTM layer l of this slot's segment has finished (state updated)
+    // host-pointer entry points (see umx_hip_infer_batch_async): the download of call k's stems is queued on the OTHER slot's
+    // stream, behind call k + 1's kernels
+    hipEvent_t k_done = nullptr;   // this slot's stems are complete (recorded on its own stream)
+    hipEvent_t out_free = nullptr; // their download has finished (recorded on the other slot's stream): overlap-add may overwrite them
+    bool out_free_valid = false;
     bool have_times = false, last_persistent = false, used = false;
 };
 } // namespace
@@ -246,6 +263,15 @@ struct umx_hip_ctx
     float *stage_in[2] = {}, *stage_out[2][4 * LSTMB_MAX_TRACKS] = {}; // per pipeline slot: device staging of the host-pointer
     int ensure_staging();                                              // entry points, [lane] / [lane][4]; allocated on first use
     hipEvent_t order_ev = nullptr;
+    struct DeferredDownload // the stems of the most recent host-pointer call, still in its slot's staging buffers
+    {
+        bool valid = false;
+        int si = 0, nb = 0, n[LSTMB_MAX_TRACKS] = {};
+        float *host[4 * LSTMB_MAX_TRACKS] = {};
+    } deferred;
+    int queue_download(const DeferredDownload &d, hipStream_t on); // D2H copies of d onto stream `on`, then out_free of its slot
+    int flush_deferred();
+    hipStream_t copy_stream = nullptr; // downloads of the host-pointer calls (created with the staging buffers)
     float *state = nullptr;
     Slot slot[2];
     int nslots = 2;
@@ -1166,8 +1192,11 @@ int umx_hip_ctx::ensure_staging()
 {
     if (stage_in[0])
         return UMX_OK;
+    UMX_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     for (int si = 0; si < 2; ++si)
     {
+        for (hipEvent_t *e : {&slot[si].k_done, &slot[si].out_free})
+            UMX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         if (int rc = dalloc(&stage_in[si], (size_t)2 * N * B, false))
             return rc;
         for (int k = 0; k < 4 * B; ++k)
@@ -1177,10 +1206,54 @@ int umx_hip_ctx::ensure_staging()
     return UMX_OK;
 }
 
+// Host-pointer calls: where the stems of call k go out.  On the slot's own stream right behind its kernels, the download
+// (48 ms for 32 lanes) stands in front of call k + 2's upload and kernels; the two slots then fall into lock step -- kernels
+// of two calls, downloads of two calls, uploads of two calls, nothing overlapping (measured with the kernel + copy trace,
+// round 3: 128 ms per step against 80 ms of kernels).  On a copy stream of its own the runtime turns the download into
+// shader blits that queue behind the persistent LSTM grids (worse: 141 ms).  So it is queued on the OTHER slot's stream
+// behind call k + 1's kernels: it then runs (on the DMA engines) beside call k + 2's kernels, whose overlap-add waits for
+// `out_free` before it reuses the staging buffers; the last call's download is queued by whoever synchronises.
+__global__ void copy_stream_marker_kernel() {}
+
+int umx_hip_ctx::queue_download(const DeferredDownload &d, hipStream_t on)
+{
+    Slot &src = slot[d.si];
+    if (on != src.stream)
+    {
+        UMX_HIP_CHECK(hipStreamWaitEvent(on, src.k_done, 0));
+        // a download that does not follow a kernel on its stream is run as shader blits by this runtime (observed, round 3):
+        // 128 copy KERNELS per step that cannot get a compute unit while a persistent LSTM grid holds all of them.  Behind a
+        // kernel -- any kernel -- the DMA engines are used, which run beside everything at the link's 55 GB/s.
+        hipLaunchKernelGGL(copy_stream_marker_kernel, dim3(1), dim3(64), 0, on);
+    }
+    for (int ln = 0; ln < d.nb; ++ln)
+        if (d.n[ln] > 0)
+            for (int s2 = 0; s2 < 4; ++s2)
+                UMX_HIP_CHECK(hipMemcpyAsync(d.host[4 * ln + s2], stage_out[d.si][4 * ln + s2], sizeof(float) * 2 * (size_t)d.n[ln],
+                                             hipMemcpyDeviceToHost, on));
+    UMX_HIP_CHECK(hipEventRecord(src.out_free, on));
+    src.out_free_valid = true;
+    return UMX_OK;
+}
+
+int umx_hip_ctx::flush_deferred()
+{
+    if (!deferred.valid)
+        return UMX_OK;
+    deferred.valid = false;
+    return queue_download(deferred, slot[deferred.si].stream);
+}
+
 int umx_hip_ctx::sync_all()
 {
+    if (int rc = flush_deferred())
+        return rc;
     for (int si = 0; si < nslots; ++si)
         UMX_HIP_CHECK(hipStreamSynchronize(slot[si].stream));
+    if (copy_stream)
+        UMX_HIP_CHECK(hipStreamSynchronize(copy_stream));
+    for (int si = 0; si < nslots; ++si)
+        slot[si].out_free_valid = false; // drained
     return UMX_OK;
 }
 
@@ -1745,6 +1818,8 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
             }
         }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
+    if (sl.out_free_valid) // the stems this slot wrote two calls ago are still being downloaded from the same buffers
+        UMX_HIP_CHECK(hipStreamWaitEvent(st, sl.out_free, 0));
     for (int ln = 0; ln < nb; ++ln)
         if (audio_dev[ln])
         {
@@ -2422,6 +2497,12 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
             (void)hipEventDestroy(e);
     if (ctx->order_ev)
         (void)hipEventDestroy(ctx->order_ev);
+    if (ctx->copy_stream)
+        (void)hipStreamDestroy(ctx->copy_stream);
+    for (int si = 0; si < 2; ++si)
+        for (hipEvent_t e : {ctx->slot[si].k_done, ctx->slot[si].out_free})
+            if (e)
+                (void)hipEventDestroy(e);
     for (int si = 0; si < 2; ++si)
     {
         Slot &sl = ctx->slot[si];
@@ -2781,7 +2862,8 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
     const int si = (int)(ctx->nseg & 1);
     if (int rc = ctx->ensure_staging())
         return rc;
-    hipStream_t st = ctx->slot[si].stream;
+    Slot &sl = ctx->slot[si];
+    hipStream_t st = sl.stream;
     const float *ain[LSTMB_MAX_TRACKS] = {};
     for (int ln = 0; ln < n_tracks; ++ln)
     {
@@ -2801,8 +2883,19 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
         }
         ain[ln] = dst;
     }
+    if (ctx->deferred.valid && ctx->deferred.si == si) // (only after a phased segment broke the alternation)
+        if (int rc = ctx->flush_deferred())
+            return rc;
     if (int rc = ctx->infer_batch(n_tracks, ain, n, ctx->stage_out[si], flags))
         return rc;
+    UMX_HIP_CHECK_CTX(ctx, hipEventRecord(sl.k_done, st));
+    static const bool on_copy_stream = !(getenv("UMX_D2H") && std::string(getenv("UMX_D2H")) == "other");
+    if (ctx->deferred.valid && !on_copy_stream) // the previous call's stems: out behind this call's kernels, beside the next call's
+    {
+        ctx->deferred.valid = false;
+        if (int rc = ctx->queue_download(ctx->deferred, st))
+            return rc;
+    }
     if (!ctx->pending_lost && !ctx->pending.empty())
     {
         for (int k = 0; k < 4 * n_tracks; ++k)
@@ -2810,18 +2903,17 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
         for (int ln = 0; ln < n_tracks; ++ln)
             ctx->pending.back().host_audio[ln] = ain[ln] ? audio_host[ln] : nullptr;
     }
+    ctx->deferred.valid = !on_copy_stream;
+    ctx->deferred.si = si;
+    ctx->deferred.nb = n_tracks;
     for (int ln = 0; ln < n_tracks; ++ln)
-        if (ain[ln])
-            for (int s = 0; s < 4; ++s)
-            {
-                hipError_t e = hipMemcpyAsync(out_host[4 * ln + s], ctx->stage_out[si][4 * ln + s], sizeof(float) * 2 * (size_t)n[ln],
-                                              hipMemcpyDeviceToHost, st);
-                if (e != hipSuccess)
-                {
-                    ctx->set_error(hipGetErrorString(e));
-                    return UMX_ERR_HIP;
-                }
-            }
+    {
+        ctx->deferred.n[ln] = ain[ln] ? n[ln] : 0;
+        for (int s = 0; s < 4; ++s)
+            ctx->deferred.host[4 * ln + s] = out_host[4 * ln + s];
+    }
+    if (on_copy_stream) // the stems go out on the copy stream as soon as they are complete, beside whatever runs next
+        return ctx->queue_download(ctx->deferred, ctx->copy_stream);
     return UMX_OK;
 }
 
