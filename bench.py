@@ -149,8 +149,10 @@ def main():
     ap.add_argument("--track-seconds", type=float, default=0.0,
                     help="also time a whole track of this length through umx_hip_shift_inference (host buffers in and "
                          "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
-    ap.add_argument("--mode", choices=["segments", "track"], default="segments",
-                    help="track: ONE 600 s track, its segments sharded over the ranks with exact LSTM state carry (config 4)")
+    ap.add_argument("--mode", choices=["segments", "track", "targets"], default="segments",
+                    help="track: ONE 600 s track, its segments sharded over the ranks with exact LSTM state carry (config 4); "
+                         "targets: the same track sharded by source model x segment (gcd(N, 4) target groups x pipeline stages)")
+    ap.add_argument("--loopback", action="store_true", help="--mode track / targets on ONE GPU: every transfer through an RCCL self send + receive")
     ap.add_argument("--gemm", choices=["planes", "bf16x3", "f32"], default=None,
                     help="dense-stack GEMM flavour: planes (default; bf16 matrix cores, pre-split operands, fp32-class accuracy), "
                          "bf16x3 (the same arithmetic, operands split while staged) or f32 MFMA")
@@ -186,7 +188,7 @@ def main():
     tmpdir = tempfile.mkdtemp(prefix=f"umx_bench_r{rank}_")
     wpath = os.path.join(tmpdir, "ggml-model-synth-u8.bin")
     pkg.ggml.write_model(wpath, pkg.ggml.synth_weights(H, seed=0), H, compress=False)
-    if args.mode == "track":
+    if args.mode in ("track", "targets"):
         return bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath)
 
     def make_engine(tracks, batched):
@@ -543,7 +545,9 @@ def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
             t = torch.frombuffer(bytearray(pkg.mgpu_unique_id()), dtype=torch.uint8).clone().to(dev)
         dist.broadcast(t, src=0)
         ids = bytes(t.cpu().numpy().tobytes())
-    drv = pkg.MultiGpuTrack(eng, rank, world, ids)
+    by_target = args.mode == "targets"
+    drv = pkg.MultiGpuTrack(eng, rank, world, ids, by_target=by_target, loopback=args.loopback and world == 1)
+    G = (4 if world % 4 == 0 else 2 if world % 2 == 0 else 1) if by_target else 1
     dd = dist if world > 1 else None
     res = [None]
 
@@ -560,13 +564,15 @@ def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
         line = {"metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg", "value": round(steps * secs / dt, 2),
                 "unit": "x realtime", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"UMX-L full-track segmented inference: one {secs:g} s track, {nseg} segments round-robin over "
-                                       f"{world} MI355X, exact LSTM state carry (per-layer (h, c) by RCCL send/recv between the engines' "
-                                       "HBM state buffers), weighted stems gathered and overlap-added on rank 0 (second communicator); "
-                                       "host buffers in and out (BASELINE config 4)",
+                "config": {"workload": f"UMX-L full-track segmented inference: one {secs:g} s track, {nseg} segments over {world} MI355X as "
+                                       f"{G} target group(s) x {world // G} segment-pipeline stage(s), exact LSTM state carry (per-layer (h, c) by "
+                                       "RCCL send/recv between the engines' HBM state buffers, sends on their own stream and communicator), "
+                                       + ("target magnitudes point to point to the rank that runs the Wiener filter of the segment, " if G > 1 else "")
+                                       + "weighted stems gathered and overlap-added on rank 0; host buffers in and out (BASELINE config 4)",
                            "hidden": args.hidden, "segment_samples": N, "segments": nseg,
-                           "parallelism": f"segments over {world} ranks, carry mode; at most 3 segments per target are in flight "
-                                          "(one per LSTM layer), so one track cannot fill more than ~3 GPUs"},
+                           "parallelism": (f"{G} target groups x {world // G} stages" if by_target else f"segments over {world} ranks, carry mode") +
+                                          "; per target at most 3 segments are in flight (one per LSTM layer)",
+                           "rccl": drv.stats()},
                 "outputs_finite": bool(all(np.isfinite(r).all() for r in res[0]))}
         print(json.dumps(line), flush=True)
     drv.close()

@@ -84,8 +84,10 @@ int umx_shift_inference(const umx_backend *be, const float *audio, int length, i
  * sample has at most two contributors), adds them exactly like umx.cpp:234-260 and normalises.  All traffic is point
  * to point; there is no collective.  Bit-identical to umx_split_inference on one rank.
  * The backend is the phased form of the per-segment call (include/umx_hip.h: umx_hip_segment_begin / _lstm_layer /
- * _end + umx_hip_stream_{get,set}_layer); the transport moves float buffers between ranks (blocking or buffered
- * sends both work: the dependency graph follows segment order).  This host-buffer form is what the CPU tests drive
+ * _end + umx_hip_stream_{get,set}_layer); the transport moves float buffers between ranks and must NOT block a send until
+ * the matching receive is posted (buffered or non-blocking sends): with two ranks, rank 0 sends layer 1 of segment 0
+ * before it receives layer 0 of segment 2, while rank 1 sends layer 0 of segment 1 before it receives layer 1 of segment
+ * 0 -- rendezvous sends would deadlock.  This host-buffer form is what the CPU tests drive
  * (torch.distributed gloo through callbacks); host/mgpu.cpp is the same schedule with device buffers over RCCL. */
 typedef struct umx_phased_backend
 {
@@ -106,6 +108,35 @@ typedef struct umx_p2p
 /* out[4] (2,length) is written on rank 0 only (may be NULL elsewhere). */
 int umx_split_inference_carry(const umx_phased_backend *be, const umx_p2p *p2p, int rank, int world, const float *audio,
                               int length, int segment_samples, float *const out[4], char *err);
+
+/* ---- one track over several ranks, sharded by SOURCE MODEL as well (BASELINE north star: "the four source models ...
+ * shard naturally").  world = G target groups x P pipeline stages, G = 4 / 2 / 1 as world is divisible by 4 / 2 / neither
+ * (host/shard_plan.h).  The per-target loop of umx_inference (inference.cpp:70-186) is independent per target until
+ * wiener_filter (inference.cpp:192-193): rank (g, p) runs the targets t % G == g of the segments s % P == p; the LSTM
+ * state of a target travels only between the stages of its own group; of the G ranks that share a segment one (rotating
+ * with the segment index) receives the other groups' target magnitudes, runs the Wiener filter + inverse STFT and sends
+ * the weighted stems to rank 0, which adds them in segment order (umx.cpp:234-273).  G = 1 is
+ * umx_split_inference_carry's schedule.  Bit-identical to umx_split_inference on one rank.
+ * The transport must not block a send until the matching receive is posted (buffered or non-blocking sends: gloo isend,
+ * MPI_Bsend / MPI_Isend): this single-threaded host form posts a rank's sends and receives in program order -- as does
+ * umx_split_inference_carry, where a rendezvous send would deadlock two ranks that send to each other.  The device form
+ * (host/mgpu.cpp) has no such requirement: it sends on a stream of its own. */
+typedef struct umx_target_backend
+{
+    int (*begin)(void *user, const float *audio, int n, unsigned target_mask); /* front of a segment for the targets in the mask */
+    int (*layer)(void *user, int l);                                   /* LSTM layer l of those targets */
+    int (*get_state)(void *user, int l, int target, float *state);     /* target_layer_floats values: [2 dirs][h, c][hidden/2] */
+    int (*set_state)(void *user, int l, int target, const float *state);
+    int (*masks)(void *user);                                          /* fc2, fc3: the target magnitudes of those targets */
+    int (*get_mag)(void *user, int target, float *mag);                /* mag_floats values, layout private to the backend */
+    int (*set_mag)(void *user, int target, const float *mag);
+    int (*finish)(void *user, float *const out[4]);                    /* Wiener + inverse STFT from all four magnitudes */
+    int (*discard)(void *user);                                        /* this rank does not filter the segment */
+    size_t target_layer_floats, mag_floats;
+    void *user;
+} umx_target_backend;
+int umx_split_inference_targets(const umx_target_backend *be, const umx_p2p *p2p, int rank, int world, const float *audio,
+                                int length, int segment_samples, float *const out[4], char *err);
 
 /* Plan of a track: the (offset, length) of every segment split_inference will run (umx.cpp:214-218),
  * used by the multi-GPU scheduler.  Returns the number of segments; fills up to cap entries. */

@@ -449,7 +449,7 @@ class Engine:
 HOST_SYMBOLS = ["umx_model_load", "umx_model_free", "umx_model_hidden", "umx_model_n_tensors", "umx_model_views",
                 "umx_model_data_bytes", "umx_model_load_progress", "umx_model_dequantize", "umx_wav_load",
                 "umx_wav_free", "umx_wav_write_f32", "umx_split_inference", "umx_shift_inference",
-                "umx_segment_plan", "umx_transition_weight", "umx_split_inference_carry"]
+                "umx_segment_plan", "umx_transition_weight", "umx_split_inference_carry", "umx_split_inference_targets"]
 
 SEGMENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int, C.POINTER(_fp))
 RESET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -467,6 +467,19 @@ class PhasedBackend(C.Structure):
     """include/umx_host.h: umx_phased_backend"""
     _fields_ = [("begin", PH_BEGIN_FN), ("layer", PH_LAYER_FN), ("end", PH_END_FN), ("get_layer", PH_STATE_FN),
                 ("set_layer", PH_STATE_FN), ("layer_floats", C.c_size_t), ("user", C.c_void_p)]
+
+
+TG_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int, C.c_uint)
+TG_STATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, _fp)
+TG_VOID_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TG_MAG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _fp)
+
+
+class TargetBackend(C.Structure):
+    """include/umx_host.h: umx_target_backend"""
+    _fields_ = [("begin", TG_BEGIN_FN), ("layer", PH_LAYER_FN), ("get_state", TG_STATE_FN), ("set_state", TG_STATE_FN),
+                ("masks", TG_VOID_FN), ("get_mag", TG_MAG_FN), ("set_mag", TG_MAG_FN), ("finish", PH_END_FN), ("discard", TG_VOID_FN),
+                ("target_layer_floats", C.c_size_t), ("mag_floats", C.c_size_t), ("user", C.c_void_p)]
 
 
 class P2P(C.Structure):
@@ -511,6 +524,8 @@ def host_lib():
                                         PROGRESS_FN, C.c_void_p, C.c_char_p]
     lib.umx_split_inference_carry.argtypes = [C.POINTER(PhasedBackend), C.POINTER(P2P), C.c_int, C.c_int, _fp, C.c_int, C.c_int,
                                               C.POINTER(_fp), C.c_char_p]
+    lib.umx_split_inference_targets.argtypes = [C.POINTER(TargetBackend), C.POINTER(P2P), C.c_int, C.c_int, _fp, C.c_int, C.c_int,
+                                                C.POINTER(_fp), C.c_char_p]
     lib.umx_segment_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     lib.umx_transition_weight.restype = C.c_float
     lib.umx_transition_weight.argtypes = [C.c_int, C.c_int, C.c_int]

@@ -3,6 +3,7 @@
 // the oracle in CPU tests).  One deliberate deviation, declared in the header: sum_weight is
 // zero-initialised over its whole length.
 #include "../../include/umx_host.h"
+#include "shard_plan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -265,6 +266,145 @@ extern "C" int umx_split_inference_carry(const umx_phased_backend *be, const umx
             sum_w[off + k] += umx_transition_weight(k, n, N);
         }
     }
+    for (int t = 0; t < 4; ++t)
+        for (int k = 0; k < length; ++k)
+        {
+            out[t][2 * (size_t)k] /= sum_w[k];
+            out[t][2 * (size_t)k + 1] /= sum_w[k];
+        }
+    return UMX_OK;
+}
+
+// ---------------------------------------------------------------- one track over several ranks, by source model x segment
+extern "C" int umx_split_inference_targets(const umx_target_backend *be, const umx_p2p *p2p, int rank, int world, const float *audio,
+                                           int length, int segment_samples, float *const out[4], char *err)
+{
+    if (!be || !be->begin || !be->layer || !be->get_state || !be->set_state || !be->masks || !be->get_mag || !be->set_mag ||
+        !be->finish || !be->discard || !audio || length < 1 || segment_samples < 2 || world < 1 || rank < 0 || rank >= world ||
+        (world > 1 && (!p2p || !p2p->send || !p2p->recv)) || (rank == 0 && !out))
+    {
+        seterr(err, "umx_split_inference_targets: bad argument");
+        return UMX_ERR_ARG;
+    }
+    const umx_plan::Plan pl = umx_plan::make_plan(world, true);
+    const int N = segment_samples, stride = (int)((1 - kOverlap) * N); // umx.cpp:181
+    std::vector<int> offsets;
+    for (long long off = 0; off < length; off += stride) // umx.cpp:214
+        offsets.push_back((int)off);
+    const int nseg = (int)offsets.size();
+    const size_t nf = be->target_layer_floats, nm = be->mag_floats;
+    unsigned mask = 0;
+    std::vector<int> mine_t;
+    for (int t = 0; t < 4; ++t)
+        if (pl.owns_target(rank, t))
+        {
+            mask |= 1u << t;
+            mine_t.push_back(t);
+        }
+    std::vector<float> st(nf), mag(nm);
+    std::vector<std::vector<float>> mine(nseg); // weighted stems of the segments this rank filters, [4][n][2]
+#define UMX_TRY(expr, what)                                                                                          \
+    if (int rc_ = (expr))                                                                                            \
+    {                                                                                                                \
+        seterr(err, std::string("target driver: ") + what + " failed (segment " + std::to_string(i) + ")");         \
+        return rc_;                                                                                                  \
+    }
+    for (int i = 0; i < nseg; ++i)
+    {
+        if (!pl.runs_segment(rank, i))
+            continue;
+        const int off = offsets[i], n = std::min(N, length - off); // umx.cpp:217
+        UMX_TRY(be->begin(be->user, audio + (size_t)2 * off, n, mask), "begin");
+        for (int l = 0; l < 3; ++l)
+        {
+            for (int t : mine_t)
+            {
+                if (i == 0) // umx.cpp:167-171 / lstm.cpp:82: the track starts from zero state
+                {
+                    std::fill(st.begin(), st.end(), 0.0f);
+                    UMX_TRY(be->set_state(be->user, l, t, st.data()), "set_state");
+                }
+                else if (pl.P > 1)
+                {
+                    UMX_TRY(p2p->recv(p2p->user, st.data(), nf, pl.prev_rank(rank, i)), "receiving LSTM state");
+                    UMX_TRY(be->set_state(be->user, l, t, st.data()), "set_state");
+                } // P == 1: the state segment i-1 left is already in place
+            }
+            UMX_TRY(be->layer(be->user, l), "LSTM layer");
+            if (pl.P > 1 && i + 1 < nseg)
+                for (int t : mine_t)
+                {
+                    UMX_TRY(be->get_state(be->user, l, t, st.data()), "get_state");
+                    UMX_TRY(p2p->send(p2p->user, st.data(), nf, pl.next_rank(rank, i)), "sending LSTM state");
+                }
+        }
+        UMX_TRY(be->masks(be->user), "masks");
+        const int wr = pl.wiener_rank(i);
+        if (wr != rank)
+        {
+            for (int t : mine_t)
+            {
+                UMX_TRY(be->get_mag(be->user, t, mag.data()), "get_mag");
+                UMX_TRY(p2p->send(p2p->user, mag.data(), nm, wr), "sending target magnitudes");
+            }
+            UMX_TRY(be->discard(be->user), "discard");
+            continue;
+        }
+        for (int t = 0; t < 4; ++t)
+            if (!pl.owns_target(rank, t))
+            {
+                UMX_TRY(p2p->recv(p2p->user, mag.data(), nm, pl.owner_of_target(t, pl.stage(rank))), "receiving target magnitudes");
+                UMX_TRY(be->set_mag(be->user, t, mag.data()), "set_mag");
+            }
+        std::vector<float> stems[4];
+        float *so[4];
+        for (int t = 0; t < 4; ++t)
+        {
+            stems[t].assign((size_t)2 * n, 0.0f);
+            so[t] = stems[t].data();
+        }
+        UMX_TRY(be->finish(be->user, so), "finish"); // wiener_filter + istft, inference.cpp:192-207
+        mine[i].resize((size_t)4 * 2 * n);
+        for (int t = 0; t < 4; ++t)
+            for (int k = 0; k < n; ++k)
+            {
+                const float w = umx_transition_weight(k, n, N); // umx.cpp:246
+                mine[i][((size_t)t * n + k) * 2] = w * stems[t][2 * (size_t)k];
+                mine[i][((size_t)t * n + k) * 2 + 1] = w * stems[t][2 * (size_t)k + 1];
+            }
+    }
+    // gather on rank 0 in segment order (= the reference's accumulation order), umx.cpp:234-273
+    if (rank != 0)
+    {
+        for (int i = 0; i < nseg; ++i)
+            if (pl.wiener_rank(i) == rank)
+                UMX_TRY(p2p->send(p2p->user, mine[i].data(), mine[i].size(), 0), "sending stems");
+        return UMX_OK;
+    }
+    std::vector<float> sum_w((size_t)length, 0.0f), buf;
+    for (int t = 0; t < 4; ++t)
+        std::fill(out[t], out[t] + (size_t)2 * length, 0.0f);
+    for (int i = 0; i < nseg; ++i)
+    {
+        const int off = offsets[i], n = std::min(N, length - off);
+        const float *ws = mine[i].data();
+        if (pl.wiener_rank(i) != 0)
+        {
+            buf.resize((size_t)4 * 2 * n);
+            UMX_TRY(p2p->recv(p2p->user, buf.data(), buf.size(), pl.wiener_rank(i)), "receiving stems");
+            ws = buf.data();
+        }
+        for (int k = 0; k < n; ++k)
+        {
+            for (int t = 0; t < 4; ++t)
+            {
+                out[t][2 * (size_t)(off + k)] += ws[((size_t)t * n + k) * 2];
+                out[t][2 * (size_t)(off + k) + 1] += ws[((size_t)t * n + k) * 2 + 1];
+            }
+            sum_w[off + k] += umx_transition_weight(k, n, N);
+        }
+    }
+#undef UMX_TRY
     for (int t = 0; t < 4; ++t)
         for (int k = 0; k < length; ++k)
         {

@@ -186,6 +186,84 @@ def separate_track_carry_mode(backend, wave, segment_samples, dist=None, rank=0,
     return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs] if rank == 0 else None
 
 
+def _torch_p2p(dist, device, guard):
+    """umx_p2p over torch.distributed: buffered sends (isend of a copy), blocking receives."""
+    import torch
+    from . import P2P, P2P_FN
+    pending = []
+
+    def _send(_u, buf, n, dst):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(n,)).copy()).to(device)
+        pending.append((dist.isend(t, dst=dst), t))  # buffered: the driver may reuse `buf` at once
+
+    def _recv(_u, buf, n, src):
+        t = torch.empty(n, dtype=torch.float32, device=device)
+        dist.recv(t, src=src)
+        np.ctypeslib.as_array(buf, shape=(n,))[:] = t.cpu().numpy()
+    cbs = (P2P_FN(guard(_send)), P2P_FN(guard(_recv)))
+    return P2P(cbs[0], cbs[1], None), cbs, pending
+
+
+def separate_track_target_mode(backend, wave, segment_samples, dist=None, rank=0, world=1, device="cpu"):
+    """Exact split of one track over `world` ranks by SOURCE MODEL x segment (include/umx_host.h:
+    umx_split_inference_targets; world = gcd(world, 4) target groups x pipeline stages); 4 x (2,L) on rank 0, else None.
+    `backend`: begin(chunk, target_mask) / layer(l) / get_state(l, t) / set_state(l, t, a) / masks() / get_mag(t) /
+    set_mag(t, a) / finish() -> 4 x (2,n) / discard() / target_layer_floats() / mag_floats().  The schedule lives in the
+    C++17 host driver; this function adapts the backend object and a torch.distributed transport to its callback tables.
+    The device-resident form (RCCL on device pointers) is host/mgpu.cpp with UMX_MGPU_BY_TARGET."""
+    import ctypes as C
+    from . import (PH_END_FN, PH_LAYER_FN, TG_BEGIN_FN, TG_MAG_FN, TG_STATE_FN, TG_VOID_FN, TargetBackend, HostError, host_lib, _fp)
+    wave = np.asarray(wave, np.float32)
+    L = wave.shape[1]
+    nf, nm = backend.target_layer_floats(), backend.mag_floats()
+    keep, failure = [], []
+
+    def guard(fn):
+        def wrapped(*a):
+            try:
+                r = fn(*a)
+                return 0 if r is None else r
+            except Exception as e:  # noqa: BLE001 - surfaced through the driver's error code
+                failure.append(e)
+                return 13
+        return wrapped
+
+    def _begin(_u, audio, n, mask):
+        backend.begin(np.ascontiguousarray(np.ctypeslib.as_array(audio, shape=(n, 2)).T), mask)
+        keep[:] = [n]
+
+    def _finish(_u, out):
+        stems = backend.finish()
+        for t in range(4):
+            np.ctypeslib.as_array(out[t], shape=(keep[0], 2))[:, :] = np.asarray(stems[t], np.float32).T
+
+    def _get_state(_u, l, t, st):
+        np.ctypeslib.as_array(st, shape=(nf,))[:] = np.asarray(backend.get_state(l, t), np.float32).ravel()
+
+    def _get_mag(_u, t, m):
+        np.ctypeslib.as_array(m, shape=(nm,))[:] = np.asarray(backend.get_mag(t), np.float32).ravel()
+    cbs = (TG_BEGIN_FN(guard(_begin)), PH_LAYER_FN(guard(lambda _u, l: backend.layer(l))), TG_STATE_FN(guard(_get_state)),
+           TG_STATE_FN(guard(lambda _u, l, t, st: backend.set_state(l, t, np.ctypeslib.as_array(st, shape=(nf,)).copy()))),
+           TG_VOID_FN(guard(lambda _u: backend.masks())), TG_MAG_FN(guard(_get_mag)),
+           TG_MAG_FN(guard(lambda _u, t, m: backend.set_mag(t, np.ctypeslib.as_array(m, shape=(nm,)).copy()))),
+           PH_END_FN(guard(_finish)), TG_VOID_FN(guard(lambda _u: backend.discard())))
+    be = TargetBackend(*cbs, nf, nm, None)
+    p2p, p2p_keep, pending = _torch_p2p(dist, device, guard) if world > 1 else (None, None, [])
+    a = np.ascontiguousarray(wave.T).ravel()
+    outs = [np.empty(2 * L, np.float32) for _ in range(4)] if rank == 0 else None
+    arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs]) if rank == 0 else None
+    err = C.create_string_buffer(256)
+    rc = host_lib().umx_split_inference_targets(C.byref(be), C.byref(p2p) if world > 1 else None, rank, world,
+                                                a.ctypes.data_as(_fp), L, segment_samples, arr, err)
+    for req, _t in pending:
+        req.wait()
+    if rc:
+        if failure:
+            raise failure[0]
+        raise HostError(rc, err.value.decode())
+    return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs] if rank == 0 else None
+
+
 def timed_region(step_fn, sync_fn, steps, warmup, dist=None, world=1, device=None):
     """bench.py's timing contract: W untimed warm-up steps, barrier + sync on both sides of exactly
     K timed steps, MAX over ranks.  Returns seconds."""
