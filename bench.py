@@ -153,9 +153,9 @@ def main():
                     help="track: ONE 600 s track, its segments sharded over the ranks with exact LSTM state carry (config 4); "
                          "targets: the same track sharded by source model x segment (gcd(N, 4) target groups x pipeline stages)")
     ap.add_argument("--loopback", action="store_true", help="--mode track / targets on ONE GPU: every transfer through an RCCL self send + receive")
-    ap.add_argument("--gemm", choices=["planes", "bf16x3", "f32"], default=None,
-                    help="dense-stack GEMM flavour: planes (default; bf16 matrix cores, pre-split operands, fp32-class accuracy), "
-                         "bf16x3 (the same arithmetic, operands split while staged) or f32 MFMA")
+    ap.add_argument("--gemm", choices=["planes", "bf16x3"], default=None,
+                    help="dense-stack GEMM flavour: planes (default; fp16 matrix cores, pre-split operands, fp32-class accuracy) or "
+                         "bf16x3 (three bf16 terms, operands split while staged)")
     ap.add_argument("--expanded-weights", action="store_true",
                     help="expand the u8/u16 weights at load time (fp32 / three bf16 planes in HBM) instead of keeping "
                          "them quantised in HBM with dequantisation inside the kernels (the default, BASELINE config 5)")

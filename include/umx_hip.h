@@ -40,7 +40,7 @@ extern "C" {
 #define UMX_FLAG_NO_WIENER 0x1      /* BASELINE config 2: mix-phase estimate only (wiener.cpp:96-109) */
 #define UMX_FLAG_SKIP_TARGET(t) (0x100 << (t)) /* BASELINE config 1 (vocals only = skip 0,1,2) */
 #define UMX_FLAG_LSTM_STEPWISE 0x10 /* one launch per timestep instead of the persistent kernel */
-#define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the mask tap (T x 4098 per target) for umx_hip_read_tap */
+#define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the filtered spectrograms for umx_hip_read_tap("y") (the fused kernel does not write them otherwise) */
 #define UMX_FLAG_LSTM_FORCE_SAFE 0x40 /* persistent kernel: never take the intra-XCD fast protocol */
 #define UMX_FLAG_LSTM_PROFILE 0x80  /* persistent kernel: record per-phase cycle counters */
 #define UMX_FLAG_DEBUG_LSTM_ABORT 0x2000 /* testing: the persistent LSTM launch of layer 1 gives up half way, exactly as if a
@@ -81,11 +81,11 @@ int umx_hip_create(umx_hip_ctx **out, int device, int hidden_size, int segment_s
  * for compatibility and is the default. */
 #define UMX_CREATE_QUANTISED_RESIDENT 0x1u
 #define UMX_CREATE_DEQUANTISE_AT_LOAD 0x8u
-/* The dense stack (fc1, W_ih, fc2, fc3 -- inference.cpp:86,127,143, lstm.cpp:132-135) runs by default on the bf16
- * matrix cores with every fp32 operand split into three bf16 terms and six products kept: the dropped terms are
- * below 2^-26 of the product, and against a float64 evaluation the result is as close as (measured: slightly
- * closer than) the fp32-MFMA kernel's, at 2.7x less matrix-core time (csrc/gemm_bf16x3.h, tools/gemm_accuracy.py).
- * UMX_CREATE_GEMM_F32 (environment UMX_GEMM=f32) selects the fp32-MFMA kernels (exact fp32 FMA chain) instead. */
+/* The dense stack (fc1, W_ih, fc2, fc3 -- inference.cpp:86,127,143, lstm.cpp:132-135) runs on the 16-bit matrix cores
+ * with split operands and fp32 accumulation (csrc/gemm_planes.h, csrc/gemm_bf16x3.h, below): the dropped terms are below
+ * 2^-22 .. 2^-26 of a product, and against a float64 evaluation the result is as close as an fp32-MFMA kernel's (measured:
+ * slightly closer; profiles/r02_accuracy_vs_float64.txt).  Rounds 1-2 also carried that fp32-MFMA flavour
+ * (UMX_CREATE_GEMM_F32): removed in round 3; the flag is now refused with UMX_ERR_ARG. */
 #define UMX_CREATE_GEMM_F32 0x4u
 /* u8-resident weights (fc1, W_ih; W_hh in the batched LSTM kernel) on the bf16 matrix cores: q - 128 is an integer in
  * [-128, 127] and EXACT in bf16 and fp16, so by default the weight is ONE term (three products with the bf16-split
@@ -242,8 +242,10 @@ int umx_hip_segment_end(umx_hip_ctx *ctx, float *const out_host[4]);
  * (inference.cpp:192-193), so a GPU runs begin / lstm_layer x 3 / masks with the other targets skipped
  * (UMX_FLAG_SKIP_TARGET), the target magnitudes travel to the GPU that filters this segment, and that GPU finishes:
  *   umx_hip_segment_masks_device   fc2, fc3, mask x |X| of the targets that are not skipped (after layer 2)
- *   umx_hip_target_mag_device      device address of target t's magnitude [2][T][2049] of the phased segment (*floats = its
- *                                  size): read it after _masks_device, or write a peer's result there before _finish_device
+ *   umx_hip_target_mag_device      device address of target t's MASK planes [2][T][2176] (2049 bins + padding per row;
+ *                                  *floats = the size) of the phased segment -- the target magnitude is mask x |X|
+ *                                  (inference.cpp:175-183), which _finish_device forms from its own spectrogram: read it
+ *                                  after _masks_device, or write a peer's result there before _finish_device
  *   umx_hip_segment_finish_device  Wiener EM (or the mixture phase), inverse STFT, overlap-add from ALL four magnitude
  *                                  buffers as they are (a skipped target is NOT zero-filled here) into 4 device buffers
  * umx_hip_segment_end_device == _masks_device, zero-fill of the skipped targets, _finish_device. */
@@ -272,8 +274,11 @@ int umx_hip_hidden(const umx_hip_ctx *ctx);
 
 /* Stage taps for parity tests (D2H copy of an intermediate of the LAST inferred segment).
  * what: "spec" [2][T][2049] complex | "mix_mag" [2][T][2049] | "x" [T][2976] |
- *       "fc1" [T][H] | "lstm" [T][H] | "fc2" [T][H] | "mask" [T][4098] (needs UMX_FLAG_DEBUG_TAPS) |
- *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex | "max_abs" [1];
+ *       "fc1" [T][H] | "lstm" [T][H] | "fc2" [T][H] | "mask" [T][4098] |
+ *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex (needs UMX_FLAG_DEBUG_TAPS) | "max_abs" [1];
+ *       ("mix_mag", "target_mag" and "mask" are not buffers of the engine any more -- fc3 writes the mask in a padded
+ *       layout and the Wiener kernels form mask x |X| in registers -- a tap kernel computes them on demand with the
+ *       device functions the hot kernels use, so they hold the bits the pipeline works with)
  *       suffix "#k" selects track lane k (default 0), "@s" pipeline slot s (default: the most recent)
  * Returns the number of floats written (or needed when dst == NULL), < 0 on error. */
 long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst, size_t capacity_floats);

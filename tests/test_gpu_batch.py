@@ -12,7 +12,8 @@ import pytest
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
-TOL_STAGE, TOL_WAVE = 2e-5, 1e-4
+TOL_STAGE, TOL_WAVE = 2e-5, 1e-4  # parity bounds (test_gpu_parity.py)
+REG_STAGE, REG_Y, REG_WAVE = 5e-6, 1e-4, 1e-5  # regression bounds beside them: measured ~1e-6 / ~3e-5 / <= 2e-6
 
 
 def _oracle_track(po, om, hidden, waves, n_buf):
@@ -162,8 +163,9 @@ def test_production_configuration_at_full_size_against_the_oracle(pkg, po, tmp_p
                                        ("mask", "mask", TOL_STAGE), ("target_mag", "target_mag", TOL_STAGE), ("y", "y", 2e-4)):
                     err = rel_l2(eng.tap(f"{name}#{b}", t), taps[key][t])
                     assert err < tol, (s, b, t, name, err)
-                assert float(np.abs(got[b][t] - ref[t]).max()) < TOL_WAVE, (s, b, t)
-            assert rel_l2(eng.track_stream_get(b), states[b]) < TOL_STAGE, (s, b)
+                    assert err < (REG_Y if name == "y" else REG_STAGE), ("regression bound", s, b, t, name, err)
+                assert float(np.abs(got[b][t] - ref[t]).max()) < REG_WAVE, (s, b, t)
+            assert rel_l2(eng.track_stream_get(b), states[b]) < REG_STAGE, (s, b)
     eng.close()
 
 
@@ -199,8 +201,9 @@ def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path
                                    ("mask", "mask", TOL_STAGE), ("target_mag", "target_mag", TOL_STAGE), ("y", "y", 2e-4)):
                 err = rel_l2(eng.tap(f"{name}#{b}", t), taps[key][t])
                 assert err < tol, (B, b, t, name, err)
-            assert float(np.abs(got[b][t] - ref[t]).max()) < TOL_WAVE, (B, b, t)
-        assert rel_l2(eng.track_stream_get(b), st) < TOL_STAGE, (B, b)
+                assert err < (REG_Y if name == "y" else REG_STAGE), ("regression bound", B, b, t, name, err)
+            assert float(np.abs(got[b][t] - ref[t]).max()) < REG_WAVE, (B, b, t)
+        assert rel_l2(eng.track_stream_get(b), st) < REG_STAGE, (B, b)
     first = {0: which.index(0), 1: which.index(1)}
     states = {k: eng.track_stream_get(first[k]) for k in (0, 1)}
     for b in range(B):

@@ -23,6 +23,10 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
 
 TOL_STAGE, TOL_Y, TOL_WAVE, MIN_SDR = 2e-5, 2e-4, 1e-4, 80.0
+# PARITY bounds above (TOL_WAVE = the reference's own 1e-4 of test_dsp.cpp).  REGRESSION bounds beside them (VERDICT round 2,
+# weak #13): what is measured is ~1e-6 per stage (rel L2), ~3e-5 on the Wiener output (the EM step amplifies rounding
+# noise ~100x) and <= 2e-6 on the waveforms, so a change that costs a decimal digit must not pass as "within parity".
+REG_STAGE, REG_Y, REG_WAVE = 5e-6, 1e-4, 1e-5
 
 
 def _check_report(rep):
@@ -30,10 +34,13 @@ def _check_report(rep):
         for k, v in r.items():
             if k.startswith(("spec", "mix_mag", "x", "fc1", "lstm[", "fc2", "mask", "target_mag", "state")):
                 assert v < TOL_STAGE, (seg, k, v)
+                assert v < REG_STAGE, ("regression bound", seg, k, v)
             elif k.startswith("y["):
                 assert v < TOL_Y, (seg, k, v)
+                assert v < REG_Y, ("regression bound", seg, k, v)
             elif k.startswith("wave_maxabs"):
                 assert v < TOL_WAVE, (seg, k, v)
+                assert v < REG_WAVE, ("regression bound", seg, k, v)
 
 
 @pytest.fixture(scope="module")
@@ -251,15 +258,8 @@ def test_quantised_resident_weights_are_bitwise_identical(pkg, model_small, tmp_
     staged = pkg.Engine.from_file(p, N, gemm="bf16x3")  # round 1's kernels keep the file's u8 / u16 bytes in HBM
     assert 130e6 < staged.weight_bytes() < 150e6
     staged.close()
-    f32 = pkg.Engine.from_file(p, N, gemm="f32", quantised_resident=False)
-    assert 440e6 < f32.weight_bytes() < 470e6
-    f32q = pkg.Engine.from_file(p, N, gemm="f32")
-    wv = pkg.ggml.synth_audio(N, 411)
-    a32, b32 = f32.infer_segment(wv), f32q.infer_segment(wv)
-    for t in range(4):
-        assert (a32[t] == b32[t]).all()
-    f32.close()
-    f32q.close()
+    with pytest.raises(pkg.UmxError):  # the fp32-MFMA flavour was removed in round 3: asking for it is an error, not a silent switch
+        pkg.Engine.from_file(p, N, gemm="f32")
     w = pkg.ggml.synth_audio(N, 410)
     a, b = ref.infer_segment(w), qr.infer_segment(w)
     assert qr.lstm_mode() == 2
@@ -315,9 +315,10 @@ def test_device_resident_track_equals_host_split_and_shift(pkg, small):
 
 
 def test_fused_wiener_istft_equals_the_unfused_kernels_bitwise(pkg, model_small, monkeypatch):
-    """csrc/wiener_istft.h (gains + filter + inverse STFT frame in one kernel, all-source statistics kernel) must give
-    the bits of the three-kernel Wiener path followed by the separate inverse STFT (UMX_WIENER=unfused), with and
-    without the EM step (BASELINE config 2), including the y tap."""
+    """csrc/wiener_istft.h (gains + filter + inverse STFT frame in one kernel: the track-batched default) must give the
+    bits of the separate filter kernel (generic complex 2x2 arithmetic, wiener_apply_kernel) followed by the separate
+    inverse STFT (UMX_WIENER=stats4: the single-track default), with and without the EM step (BASELINE config 2),
+    including the y tap."""
     import torch
     torch.zeros(1).cuda()
     path, om, targets = model_small
@@ -325,22 +326,21 @@ def test_fused_wiener_istft_equals_the_unfused_kernels_bitwise(pkg, model_small,
     wave = pkg.ggml.synth_audio(N, 77)
     for flags in (pkg.FLAG_DEBUG_TAPS, pkg.FLAG_DEBUG_TAPS | pkg.FLAG_NO_WIENER):
         res = {}
-        for mode in ("unfused", "fused"):
+        for mode in ("stats4", "fused"):
             monkeypatch.setenv("UMX_WIENER", mode)
             eng = pkg.Engine(targets, 128, N)
             res[mode] = (eng.infer_segment(wave, flags), [eng.tap("y", t) for t in range(4)])
             eng.close()
         for t in range(4):
-            assert np.array_equal(res["fused"][0][t], res["unfused"][0][t])
-            assert np.array_equal(res["fused"][1][t], res["unfused"][1][t])
+            assert np.array_equal(res["fused"][0][t], res["stats4"][0][t])
+            assert np.array_equal(res["fused"][1][t], res["stats4"][1][t])
 
 
-def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_path):
-    """The dense stack runs on the bf16 matrix cores (fp32 activations split into three bf16 terms, fp32 accumulation):
-    gemm="bf16x3" splits while it stages every tile (csrc/gemm_bf16x3.h, the single-track default), gemm="planes" consumes
-    pre-split operands by LDS-DMA (csrc/gemm_planes.h, the track-batched default); gemm="f32" keeps the fp32-MFMA
-    kernels.  All must sit within the same distance of the oracle, agree with each other to fp32 rounding, and -- for
-    every flavour -- queuing segments back to back must give the bits of one segment at a time (co-residency of bf16
+def test_gemm_flavours_agree(pkg, po, model_small, tmp_path):
+    """The dense stack runs on the 16-bit matrix cores with split operands and fp32 accumulation: gemm="bf16x3" splits into
+    three bf16 terms while it stages every tile (csrc/gemm_bf16x3.h, the single-track default), gemm="planes" consumes
+    operands pre-split into fp16 planes by LDS-DMA (csrc/gemm_planes.h, the track-batched default).  Both must sit within
+    the same distance of the oracle, agree with each other to fp32 rounding, and -- for either flavour -- queuing segments back to back must give the bits of one segment at a time (co-residency of bf16
     MFMA waves with other kernels' waves is what this guards)."""
     import torch
     torch.zeros(1).cuda()
@@ -350,7 +350,7 @@ def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_pat
     state = po.stream_state(128)
     ref = [po.umx_inference(om, w, n_buf=N, state=state)[0] for w in waves]
     outs = {}
-    for gemm in ("bf16x3", "planes", "f32"):
+    for gemm in ("bf16x3", "planes"):
         eng = pkg.Engine(targets, 128, N, gemm=gemm)
         outs[gemm] = [eng.infer_segment(w) for w in waves]
         eng.close()
@@ -359,15 +359,14 @@ def test_gemm_flavours_agree_and_fp32_path_is_kept(pkg, po, model_small, tmp_pat
                 assert np.abs(outs[gemm][i][t] - ref[i][t]).max() < TOL_WAVE
     for i in range(2):
         for t in range(4):
-            assert np.abs(outs["bf16x3"][i][t] - outs["f32"][i][t]).max() < 1e-5
-            assert np.abs(outs["planes"][i][t] - outs["f32"][i][t]).max() < 1e-5
+            assert np.abs(outs["bf16x3"][i][t] - outs["planes"][i][t]).max() < 1e-5
     # UMX-L width, pipelined == serial, both flavours
     H, N, NSEG = 1024, 40 * 1024, 6
     p = str(tmp_path / "m.bin")
     pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=33), H, compress=False)
     waves = [pkg.ggml.synth_audio(N, 610 + i) for i in range(NSEG)]
     ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda() for w in waves]
-    for gemm in ("bf16x3", "planes", "f32"):
+    for gemm in ("bf16x3", "planes"):
         eng = pkg.Engine.from_file(p, N, gemm=gemm)
         eng.stream_reset()
         serial = [eng.infer_segment(w) for w in waves]

@@ -10,7 +10,7 @@ H, N, NSEG = 1024, 40 * 1024, 8
 d = tempfile.mkdtemp()
 p = f"{d}/m.bin"
 pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=29), H, compress=False)
-eng = pkg.Engine.from_file(p, N, gemm="bf16x3" if os.environ.get("BX", "1") == "1" else "f32")
+eng = pkg.Engine.from_file(p, N, gemm="bf16x3" if os.environ.get("BX", "1") == "1" else "planes")
 lib = eng.lib
 lib.umx_hip_debug_lds_guard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint)]
 waves = [pkg.ggml.synth_audio(N, 200 + i) for i in range(NSEG)]

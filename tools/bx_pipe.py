@@ -11,7 +11,7 @@ d = tempfile.mkdtemp()
 p = f"{d}/m.bin"
 pkg.ggml.write_model(p, pkg.ggml.synth_weights(H, seed=29), H, compress=False)
 import os
-eng = pkg.Engine.from_file(p, N, gemm="bf16x3" if os.environ.get("BX", "1") == "1" else "f32")
+eng = pkg.Engine.from_file(p, N, gemm="bf16x3" if os.environ.get("BX", "1") == "1" else "planes")
 waves = [pkg.ggml.synth_audio(N, 200 + i) for i in range(NSEG)]
 eng.stream_reset()
 serial = [eng.infer_segment(w, int(os.environ.get('FL', '0'), 0)) for w in waves]

@@ -43,7 +43,7 @@ def run(**kw):
     return r
 
 
-res = {"planes": run(gemm="planes"), "bf16x3": run(gemm="bf16x3"), "f32 MFMA": run(gemm="f32"),
+res = {"planes": run(gemm="planes"), "bf16x3": run(gemm="bf16x3"),
        "planes+batched LSTM": run(gemm="planes", tracks=2)}
 oracle = {"fc1": taps["fc1_out"], "lstm": taps["lstm_out"], "fc2": taps["fc2_out"]}
 

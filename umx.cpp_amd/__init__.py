@@ -196,9 +196,9 @@ class Engine:
                  quantised_resident=True, gemm=None, tracks=1, lstm_batched=False, u8_dequant=False):
         """quantised: hand the file's u8/u16 bytes (+ scale/offset) to the engine instead of fp32 arrays;
         quantised_resident: keep them that way in HBM (the default; BASELINE config 5) or expand them at load;
-        gemm: "planes" (bf16 matrix cores, operands pre-split into bf16 planes, LDS-DMA staging: the default with tracks > 1
-        or lstm_batched), "bf16x3" (the same arithmetic with both operands split while every tile is staged: the default of
-        the single-track engine) or "f32" (fp32 MFMA);
+        gemm: "planes" (fp16 matrix cores, operands pre-split into fp16 planes, LDS-DMA staging: the default with tracks > 1
+        or lstm_batched) or "bf16x3" (bf16 terms, both operands split while every tile is staged: the default of the
+        single-track engine); "f32" (the fp32-MFMA flavour of rounds 1-2) is refused;
         tracks: independent track lanes (1..16) run together per call (infer_batch*);
         lstm_batched: use the batched (matrix-core) LSTM kernel also on a 1-track context."""
         self.lib = hip_lib()

@@ -15,7 +15,9 @@ constexpr int CROP = 1487;  // inference.cpp:55
 constexpr int NIN = 2974;   // inference.cpp:41
 constexpr int KX = 2976;    // NIN padded to a multiple of 32 (GEMM K tile)
 constexpr int NOUT = 4098;  // inference.cpp:53
-constexpr int NOUT_PAD = 4352; // NOUT padded to a multiple of 256 (largest GEMM N tile)
+constexpr int NOUT_PAD = 4352; // fc3's N: two channels of MAGP columns (a multiple of 256, the largest GEMM N tile)
+constexpr int MAGP = 2176;     // row pitch of the mask planes [2][T][MAGP] fc3 writes (2049 bins + padding): 17 x 128 floats,
+                               // so that a frame's row starts on a 128-byte line and a wave stores whole lines
 constexpr int WIENER_BATCH = 200; // wiener.hpp:16
 constexpr float WIENER_EPS = 1e-10f;  // wiener.hpp:12
 constexpr float WIENER_SCALE = 10.0f; // wiener.hpp:13
@@ -34,6 +36,12 @@ __device__ __forceinline__ float div_by(float a, float b, float rcp_b)
     const float q = a * rcp_b;
     return fmaf(fmaf(-q, b, a), rcp_b, q);
 }
+
+// |X| of one bin exactly as inference.cpp:29 forms it (std::abs of a complex float = hypotf): ONE definition, so that the
+// network input x, the mask x |X| products of the Wiener kernels (inference.cpp:175-183) and the debug taps hold the same bits
+__device__ __forceinline__ float mix_magnitude(float2 z) { return hypotf(z.x, z.y); }
+// element (channel c, frame f, bin b) of a mask plane [2][T][MAGP]
+__device__ __forceinline__ size_t mask_index(int c, int T, int f, int b) { return ((size_t)c * T + f) * MAGP + b; }
 
 } // namespace umx
 

@@ -22,7 +22,6 @@
 #include <vector>
 
 #include "common.h"
-#include "gemm_kernels.h"
 #include "gemm_bf16x3.h"
 #include "gemm_planes.h"
 #include "lstm_kernels.h"
@@ -83,8 +82,8 @@ struct TargetBufs // weights of one target (shared by both pipeline slots)
 
 struct TargetAct // activations of one target in one pipeline slot
 {
-    float *cat = nullptr, *la = nullptr, *lb = nullptr, *P = nullptr, *a2 = nullptr, *mag = nullptr,
-          *mask_dbg = nullptr;
+    float *cat = nullptr, *la = nullptr, *lb = nullptr, *P = nullptr, *a2 = nullptr,
+          *mag = nullptr; // mag: fc3's MASK [2][T][MAGP]; x |X| = the target magnitude, formed by the consumers (gemm_common.h)
     // gemm_planes.h: every GEMM's A operand split once into two fp16 planes of the scaled row, its row sums and (for the
     // unbounded tensors) its per-row inverse scales
     unsigned short *xs_p = nullptr, *cat_p = nullptr, *la_p = nullptr, *lb_p = nullptr, *a2_p = nullptr;
@@ -118,7 +117,7 @@ struct Lane
 {
     TargetAct ta[4];
     float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
-    float *mix_mag = nullptr, *x = nullptr, *wpart = nullptr, *R = nullptr, *Rc = nullptr;
+    float *x = nullptr, *wpart = nullptr, *R = nullptr, *Rc = nullptr;
     unsigned *maxabs = nullptr;
 };
 
@@ -259,6 +258,7 @@ struct umx_hip_ctx
     float *whh[3] = {}, *bhh[3] = {};
     float *window = nullptr, *nw = nullptr;
     float2 *tw1 = nullptr, *tw2 = nullptr;
+    float *tap_tmp = nullptr;                    // umx_hip_read_tap: scratch of the computed taps
     float *audio_in = nullptr, *out_dev[4] = {}; // device staging of the phased (multi-GPU carry) entry points
     float *stage_in[2] = {}, *stage_out[2][4 * LSTMB_MAX_TRACKS] = {}; // per pipeline slot: device staging of the host-pointer
     int ensure_staging();                                              // entry points, [lane] / [lane][4]; allocated on first use
@@ -341,7 +341,6 @@ struct umx_hip_ctx
     size_t weight_bytes = 0;      // HBM held by model tensors (the config-5 figure of merit)
     bool gemm_bf16x3 = false;     // dense stack on the bf16 matrix cores, three-term split (gemm_bf16x3.h)
     bool wiener_fused = true;     // wiener_istft.h: gains + filter + inverse STFT frame in one kernel
-    bool wiener_stats4 = true;    // all-source statistics kernel (wiener_kernels.h)
     bool gemm_planes = false;     // ... with both operands pre-split / re-encoded as bf16 planes and LDS-DMA staging (gemm_planes.h)
     void launch_split(Lane &ln, int nl, hipStream_t st, int which, const int *active, int nact);
     void launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
@@ -559,17 +558,19 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         return true;
     };
 
-    gemm_bf16x3 = !(create_flags & UMX_CREATE_GEMM_F32); // the bf16 matrix cores are the default
+    if (create_flags & UMX_CREATE_GEMM_F32)
+    {
+        set_error("UMX_CREATE_GEMM_F32: the fp32-MFMA GEMM flavour was removed in round 3 (slower and, against float64, less accurate "
+                  "than the split-operand kernels: profiles/r02_accuracy_vs_float64.txt)");
+        return UMX_ERR_ARG;
+    }
+    gemm_bf16x3 = true; // 16-bit matrix cores with split operands: gemm_planes.h or gemm_bf16x3.h
     // Track-batched contexts fuse the Wiener filter with the inverse STFT (wiener_istft.h: one 1024-thread, 136 KB-LDS
     // workgroup per frame); the single-track context keeps the small kernels, which run beside the other slot's LSTM
     // grids (measured: fused 7.85 ms per segment in the pipeline, unfused 7.41).  UMX_WIENER = fused | stats4 | unfused.
     wiener_fused = lstm_batched;
-    wiener_stats4 = true;
-    if (const char *e = getenv("UMX_WIENER"))
-    {
+    if (const char *e = getenv("UMX_WIENER")) // fused | stats4 (= statistics kernel + separate filter and inverse-STFT kernels)
         wiener_fused = std::string(e) == "fused";
-        wiener_stats4 = std::string(e) != "unfused";
-    }
     // gemm_planes.h for track-batched contexts (large tiles over all lanes); gemm_bf16x3.h for the single-track,
     // latency-optimised context, whose pipeline overlaps small GEMM blocks with two co-resident LSTM grids (the register
     // and LDS budget of DESIGN 4.2 was tuned for exactly that kernel).  Either can be forced.
@@ -683,16 +684,19 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             return rc;
         if (!get(tg, "output_scale", NBINS, v))
             return UMX_ERR_MODEL;
+        // fc3's columns: channel c at [c * MAGP, c * MAGP + 2049) (gemm_common.h); model.cpp:240-290 duplicates per channel
         w.assign(NOUT_PAD, 0.f);
-        for (int k = 0; k < NOUT; ++k)
-            w[k] = v[k % NBINS];
+        for (int c = 0; c < 2; ++c)
+            for (int k = 0; k < NBINS; ++k)
+                w[c * MAGP + k] = v[k];
         if (int rc = upload(&b.out_scale, w))
             return rc;
         if (!get(tg, "output_mean", NBINS, v))
             return UMX_ERR_MODEL;
         w.assign(NOUT_PAD, 0.f);
-        for (int k = 0; k < NOUT; ++k)
-            w[k] = v[k % NBINS];
+        for (int c = 0; c < 2; ++c)
+            for (int k = 0; k < NBINS; ++k)
+                w[c * MAGP + k] = v[k];
         if (int rc = upload(&b.out_mean, w))
             return rc;
         // fc1 (H x 2974) -> (H x KX), zero K padding
@@ -750,7 +754,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (!get(tg, std::string("bn3.") + bnn[k], NOUT, v))
                 return UMX_ERR_MODEL;
             w.assign(NOUT_PAD, k == 1 ? 1.f : 0.f); // padded running_var = 1: no 0/0 in dead columns
-            memcpy(w.data(), v.data(), sizeof(float) * NOUT);
+            for (int c = 0; c < 2; ++c)
+                memcpy(&w[c * MAGP], &v[c * NBINS], sizeof(float) * NBINS);
             if (int rc = upload(&b.bn3[k], w))
                 return rc;
         }
@@ -790,13 +795,34 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = upload_matrix(&b.fc2_w, &b.fc2_bx, v))
                 return rc;
         }
+        // fc3's output rows in the column layout of the mask planes: channel c's 2049 rows at [c * MAGP, ...), zero rows between
+        std::vector<unsigned char> fc3_perm;
+        umx_tensor_view fc3_tv;
+        memset(&fc3_tv, 0, sizeof fc3_tv);
+        if (const umx_tensor_view *tv = view(tg, "fc3.weight"); tv && tv->dtype == UMX_DTYPE_U16 && nelems(tv) == (size_t)NOUT * H)
+        {
+            fc3_perm.assign((size_t)NOUT_PAD * H * 2, 0);
+            for (int c = 0; c < 2; ++c)
+                memcpy(&fc3_perm[(size_t)c * MAGP * H * 2], static_cast<const unsigned char *>(tv->data) + (size_t)c * NBINS * H * 2, (size_t)NBINS * H * 2);
+            fc3_tv = *tv;
+            fc3_tv.data = fc3_perm.data();
+        }
+        auto fc3_f32 = [&](std::vector<float> &dst) -> bool { // dequantised fp32, permuted, (NOUT_PAD x H)
+            std::vector<float> src;
+            if (!get(tg, "fc3.weight", (size_t)NOUT * H, src))
+                return false;
+            dst.assign((size_t)NOUT_PAD * H, 0.f);
+            for (int c = 0; c < 2; ++c)
+                memcpy(&dst[(size_t)c * MAGP * H], &src[(size_t)c * NBINS * H], sizeof(float) * (size_t)NBINS * H);
+            return true;
+        };
         if (gemm_planes)
         {
             std::vector<unsigned short> host;
-            const umx_tensor_view *tv = view(tg, "fc3.weight");
+            const umx_tensor_view *tv = fc3_tv.data ? &fc3_tv : nullptr;
             if (exact_ok && all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
             {
-                fill_planes(host, 2, NOUT_PAD, H, tv, nullptr, NOUT, H, nullptr, 0);
+                fill_planes(host, 2, NOUT_PAD, H, tv, nullptr, NOUT_PAD, H, nullptr, 0);
                 b.fc3_p.s[0] = tv->scale;
                 b.fc3_p.o2[0] = tv->offset + 32896.0f * tv->scale;
                 if (int rc = upload_pmat(b.fc3_p, host, 2))
@@ -804,16 +830,16 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             }
             else
             {
-                if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
+                if (!fc3_f32(v))
                     return UMX_ERR_MODEL;
-                b.fc3_p.s[0] = fill_planes(host, 2, NOUT_PAD, H, nullptr, v.data(), NOUT, H, nullptr, 0);
+                b.fc3_p.s[0] = fill_planes(host, 2, NOUT_PAD, H, nullptr, v.data(), NOUT_PAD, H, nullptr, 0);
                 if (int rc = upload_pmat(b.fc3_p, host, 2))
                     return rc;
             }
         }
-        else if (const umx_tensor_view *tv = view(tg, "fc3.weight"); all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
+        else if (const umx_tensor_view *tv = &fc3_tv; all_q("fc3.weight", UMX_DTYPE_U16, (size_t)NOUT * H))
         {
-            if (int rc = upload_q(&b.fc3_q.q, tv, NOUT, H, NOUT_PAD, H, nullptr, 0, NOUT_PAD))
+            if (int rc = upload_q(&b.fc3_q.q, tv, NOUT_PAD, H, NOUT_PAD, H, nullptr, 0, NOUT_PAD))
                 return rc;
             b.fc3_q.type = BQ_U16;
             b.fc3_q.s[0] = tv->scale;
@@ -821,10 +847,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         }
         else
         {
-            if (!get(tg, "fc3.weight", (size_t)NOUT * H, v))
+            if (!fc3_f32(w))
                 return UMX_ERR_MODEL;
-            w.assign((size_t)NOUT_PAD * H, 0.f);
-            memcpy(w.data(), v.data(), sizeof(float) * (size_t)NOUT * H);
             if (int rc = upload_matrix(&b.fc3_w, &b.fc3_bx, w))
                 return rc;
         }
@@ -986,10 +1010,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         UMX_HIP_CHECK(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
         // Buffers that a launch covering several track lanes reads or writes (the batched LSTM kernel, the plane GEMMs
         // with M = lanes x Tp) are ONE allocation per slot (and target), lane after lane at a constant stride.
-        float *x_all = nullptr, *mixmag_all = nullptr;
+        float *x_all = nullptr;
         if (int rc = dalloc(&x_all, ((size_t)B * Tp + Mpad) * KX))
-            return rc;
-        if (int rc = dalloc(&mixmag_all, (size_t)B * 2 * T * NBINS))
             return rc;
         for (int tg = 0; tg < 4; ++tg)
         {
@@ -1004,7 +1026,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 return rc;
             if (int rc = dalloc(&a2_all, ((size_t)B * Tp + Mpad) * H))
                 return rc;
-            if (int rc = dalloc(&mag_all, (size_t)B * 2 * T * NBINS))
+            if (int rc = dalloc(&mag_all, (size_t)B * 2 * T * MAGP))
                 return rc;
             unsigned short *xs_p = nullptr, *cat_p = nullptr, *la_p = nullptr, *lb_p = nullptr, *a2_p = nullptr;
             float *rs[8] = {};
@@ -1029,7 +1051,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 b.lb = lb_all + (size_t)ln * Tp * H;
                 b.P = P_all + (size_t)ln * Tp * 4 * H;
                 b.a2 = a2_all + (size_t)ln * Tp * H;
-                b.mag = mag_all + (size_t)ln * 2 * T * NBINS;
+                b.mag = mag_all + (size_t)ln * 2 * T * MAGP;
                 if (gemm_planes) // lane ln's rows start at row ln * Tp of every plane
                 {
                     b.xs_p = xs_p + (size_t)ln * Tp * KX;
@@ -1052,7 +1074,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         {
             Lane &L = sl.lane[ln];
             L.x = x_all + (size_t)ln * Tp * KX;
-            L.mix_mag = mixmag_all + (size_t)ln * 2 * T * NBINS;
             if (int rc = dalloc(&L.spec, (size_t)2 * T * NBINS))
                 return rc;
             if (int rc = dalloc(&L.y, (size_t)4 * 2 * T * NBINS))
@@ -1144,16 +1165,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     }
     // dynamic LDS > 64 KiB must be opted into
     {
-        const void *gemms[8] = {reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1, BQ_F32>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC1, BQ_U8>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_IH, BQ_F32>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_IH, BQ_U8>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC2, BQ_F32>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC2, BQ_U16>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3, BQ_F32>),
-                                reinterpret_cast<const void *>(gemm_tn_kernel<G_FC3, BQ_U16>)};
-        for (const void *fn : gemms)
-            UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
         const void *bxs[10] = {reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_U8X>),
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_IH, BQ_U8X>),
                               reinterpret_cast<const void *>(gemm_bf16x3_kernel<G_FC1, BQ_F32>),
@@ -1473,7 +1484,7 @@ void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, con
         default:
             t.A = c.a2; t.B = b.fc3_w; t.C = c.mag;
             t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
-            t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = sl.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
+            t.q0 = b.out_scale; t.q1 = b.out_mean;
             g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0;
             break;
         }
@@ -1503,8 +1514,7 @@ void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, con
         }
     const dim3 grid((unsigned)round_up((g.N / GEMM_BN) * (g.M / GEMM_BM), 8), 1, nact), block(256);
 #define UMX_LAUNCH(KERNEL, LDS) hipLaunchKernelGGL((KERNEL), grid, block, LDS, st, g)
-    if (gemm_bf16x3)
-        switch (mode)
+    switch (mode)
         {
         case G_FC1:
             if (bq == BQ_U8 && !u8_dequant) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC1, BQ_U8X>), BX_LDS_BYTES);
@@ -1523,26 +1533,6 @@ void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, con
         default:
             if (bq == BQ_U16) UMX_LAUNCH((gemm_bf16x3_kernel<G_FC3, BQ_U16>), BX_LDS_BYTES);
             else UMX_LAUNCH((gemm_bf16x3_kernel<G_FC3, BQ_F32>), BX_LDS_BYTES);
-            break;
-        }
-    else
-        switch (mode)
-        {
-        case G_FC1:
-            if (bq == BQ_U8) UMX_LAUNCH((gemm_tn_kernel<G_FC1, BQ_U8>), GEMM_LDS_BYTES);
-            else UMX_LAUNCH((gemm_tn_kernel<G_FC1, BQ_F32>), GEMM_LDS_BYTES);
-            break;
-        case G_IH:
-            if (bq == BQ_U8) UMX_LAUNCH((gemm_tn_kernel<G_IH, BQ_U8>), GEMM_LDS_BYTES);
-            else UMX_LAUNCH((gemm_tn_kernel<G_IH, BQ_F32>), GEMM_LDS_BYTES);
-            break;
-        case G_FC2:
-            if (bq == BQ_U16) UMX_LAUNCH((gemm_tn_kernel<G_FC2, BQ_U16>), GEMM_LDS_BYTES);
-            else UMX_LAUNCH((gemm_tn_kernel<G_FC2, BQ_F32>), GEMM_LDS_BYTES);
-            break;
-        default:
-            if (bq == BQ_U16) UMX_LAUNCH((gemm_tn_kernel<G_FC3, BQ_U16>), GEMM_LDS_BYTES);
-            else UMX_LAUNCH((gemm_tn_kernel<G_FC3, BQ_F32>), GEMM_LDS_BYTES);
             break;
         }
 #undef UMX_LAUNCH
@@ -1601,8 +1591,7 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     g.lanes = nl;
     g.T = T;
     g.Tp_lane = Tp;
-    g.mag_lane = (size_t)2 * T * NBINS;
-    g.dbg_lane = (size_t)T * NOUT;
+    g.mag_lane = (size_t)2 * T * MAGP;
     g.a_unscale = 1.0f / (float)(1 << GP_SPLIT_FIXED_EXP); // tanh / LSTM outputs: constant scale (split_planes_kernel)
     const size_t rows_all = (size_t)B * Tp + Mpad;
     int nbp = 2;
@@ -1640,7 +1629,7 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
             pm = &b.fc3_p;
             t.A = c.a2_p; t.C = c.mag; t.rs0 = c.rs_a2; t.rsc = c.rsc_a2;
             t.e0 = b.bn3[0]; t.e1 = b.bn3[1]; t.e2 = b.bn3[2]; t.e3 = b.bn3[3];
-            t.q0 = b.out_scale; t.q1 = b.out_mean; t.aux = ln.mix_mag; t.dbg = dbg ? c.mask_dbg : nullptr;
+            t.q0 = b.out_scale; t.q1 = b.out_mean;
             g.N = NOUT_PAD; g.K = H; g.lda = H; g.ldc = 0; g.a_plane = rows_all * H;
             break;
         }
@@ -1709,8 +1698,7 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
         {
             Lane &L = sl.lane[ln];
             UMX_HIP_CHECK(hipMemsetAsync(L.maxabs, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev[ln], n[ln], N, T, window, tw1, tw2, L.spec,
-                               L.mix_mag, L.x, L.maxabs);
+            hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev[ln], n[ln], N, T, window, tw1, tw2, L.spec, L.x, L.maxabs);
         }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC1, 0, active, nact, false);
@@ -1748,7 +1736,7 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
             if (audio_dev[ln])
                 for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
                     if (flags & UMX_FLAG_SKIP_TARGET(tg))
-                        UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * NBINS, st));
+                        UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * MAGP, st));
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_WIENER], st));
     const int bt = (NBINS + 255) / 256;
     for (int ln = 0; ln < nb; ++ln)
@@ -1770,7 +1758,6 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
         }
         else
         {
-            if (wiener_stats4) // all four sources per thread, prefetched (same bits as the per-source kernel)
             {
                 static const int ns = getenv("UMX_WIENER_NS") ? atoi(getenv("UMX_WIENER_NS")) : 2; // sources per thread (measured: 4: 0.151, 2: 0.128, 1: 0.131 ms per track)
                 const dim3 g((NBINS + 63) / 64, nchunk, 4 / (ns == 1 || ns == 2 ? ns : 4));
@@ -1781,12 +1768,6 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
                 else
                     hipLaunchKernelGGL(wiener_stats4_kernel<4>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
                 hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, T, L.Rc, wiener_fused ? nullptr : L.R);
-            }
-            else
-            {
-                hipLaunchKernelGGL(wiener_stats_kernel, dim3(bt, nbatch, 4), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.wpart,
-                                   nbatch);
-                hipLaunchKernelGGL(wiener_finish_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, nbatch, L.R);
             }
             if (!wiener_fused)
                 hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
@@ -1890,17 +1871,6 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
     hipStream_t st = sl.stream;
     int active[4], nact;
     active_list(flags, active, nact);
-    const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
-    if (dbg)
-        for (int tg = 0; tg < 4; ++tg)
-            if (!sl.lane[0].ta[tg].mask_dbg)
-            {
-                float *all = nullptr;
-                if (int rc = dalloc(&all, (size_t)B * T * NOUT))
-                    return rc;
-                for (int ln = 0; ln < B; ++ln)
-                    sl.lane[ln].ta[tg].mask_dbg = all + (size_t)ln * T * NOUT;
-            }
     last_flags = flags;
     const size_t call_idx = pending_lost ? (size_t)kBackupCalls : pending.size();
     if (call_idx >= (size_t)kBackupCalls)
@@ -2356,6 +2326,32 @@ int umx_hip_ctx::phase_end(float *const out_host[4])
     return UMX_OK;
 }
 
+// ---------------------------------------------------------------- debug taps of what is no longer materialised
+// |X| (the STFT kernel keeps only the cropped part the network reads), the target magnitude mask x |X| (formed inside the
+// Wiener kernels) and the mask in the reference's (T, 4098) shape: computed on demand, with the SAME device functions the
+// hot kernels use (mix_magnitude, common.h), so a tap holds the bits the pipeline works with.
+__global__ __launch_bounds__(256) void tap_mix_mag_kernel(const float2 *__restrict__ spec, size_t n, float *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        out[i] = mix_magnitude(spec[i]);
+}
+__global__ __launch_bounds__(256) void tap_target_mag_kernel(const float2 *__restrict__ spec, const float *__restrict__ mask, size_t n,
+                                                             float *__restrict__ out) // [2][T][2049]
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        out[i] = mask[(i / NBINS) * MAGP + i % NBINS] * mix_magnitude(spec[i]); // inference.cpp:175-183
+}
+__global__ __launch_bounds__(256) void tap_mask_kernel(const float *__restrict__ mask, int T, float *__restrict__ out) // [T][4098]
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)T * NOUT)
+        return;
+    const int t = (int)(i / NOUT), k = (int)(i % NOUT), c = k >= NBINS ? 1 : 0;
+    out[i] = mask[mask_index(c, T, t, k - c * NBINS)];
+}
+
 // ---------------------------------------------------------------- debugging: LDS isolation guard
 // A victim workgroup fills 36 KB of LDS with a pattern and keeps verifying it for a while; run beside other
 // kernels it shows whether anything else writes into its LDS allocation.
@@ -2685,7 +2681,7 @@ float *umx_hip_target_mag_device(umx_hip_ctx *ctx, int target, size_t *floats)
     if (!ctx || target < 0 || target > 3)
         return nullptr;
     if (floats)
-        *floats = (size_t)2 * ctx->T * NBINS;
+        *floats = (size_t)2 * ctx->T * MAGP;
     return ctx->slot[0].lane[0].ta[target].mag;
 }
 int umx_hip_gate_reserve(int device, int cus)
@@ -2976,8 +2972,9 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
     const Lane &sl = ctx->slot[which].lane[lane];
     const void *src = nullptr;
     size_t nfl = 0, src_ld = 0, rows = 0, cols = 0; // strided copy when src_ld != cols
+    int computed = 0; // 1 |X|, 2 mask x |X|, 3 mask as (T, 4098): formed by a tap kernel into ctx->tap_tmp
     if (w == "spec") { src = sl.spec; nfl = (size_t)2 * 2 * T * NBINS; }
-    else if (w == "mix_mag") { src = sl.mix_mag; nfl = (size_t)2 * T * NBINS; }
+    else if (w == "mix_mag") { src = sl.spec; computed = 1; nfl = (size_t)2 * T * NBINS; }
     else if (w == "x") { src = sl.x; nfl = (size_t)T * KX; }
     else if (w == "fc1") { src = sl.ta[target].cat; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
     else if (w == "lstm") { src = sl.ta[target].cat + H; rows = T; cols = H; src_ld = 2 * H; nfl = rows * cols; }
@@ -2985,8 +2982,8 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
     else if (w == "lstm_l1") { src = sl.ta[target].lb; nfl = (size_t)T * H; }
     else if (w == "proj") { src = sl.ta[target].P; nfl = (size_t)T * 4 * H; }
     else if (w == "fc2") { src = sl.ta[target].a2; nfl = (size_t)T * H; }
-    else if (w == "mask") { src = sl.ta[target].mask_dbg; nfl = (size_t)T * NOUT; }
-    else if (w == "target_mag") { src = sl.ta[target].mag; nfl = (size_t)2 * T * NBINS; }
+    else if (w == "mask") { src = sl.ta[target].mag; computed = 3; nfl = (size_t)T * NOUT; }
+    else if (w == "target_mag") { src = sl.ta[target].mag; computed = 2; nfl = (size_t)2 * T * NBINS; }
     else if (w == "y") { src = sl.y + (size_t)target * 2 * T * NBINS; nfl = (size_t)2 * 2 * T * NBINS; }
     else if (w == "max_abs") { src = sl.maxabs; nfl = 1; }
     else return -1;
@@ -2998,6 +2995,21 @@ long umx_hip_read_tap(umx_hip_ctx *ctx, const char *what, int target, float *dst
         return -3;
     if (ctx->sync_all() != UMX_OK)
         return -4;
+    if (computed)
+    {
+        if (!ctx->tap_tmp && ctx->dalloc(&ctx->tap_tmp, (size_t)2 * T * NBINS) != UMX_OK)
+            return -4;
+        const unsigned blocks = (unsigned)((nfl + 255) / 256);
+        if (computed == 1)
+            hipLaunchKernelGGL(tap_mix_mag_kernel, dim3(blocks), dim3(256), 0, nullptr, sl.spec, nfl, ctx->tap_tmp);
+        else if (computed == 2)
+            hipLaunchKernelGGL(tap_target_mag_kernel, dim3(blocks), dim3(256), 0, nullptr, sl.spec, sl.ta[target].mag, nfl, ctx->tap_tmp);
+        else
+            hipLaunchKernelGGL(tap_mask_kernel, dim3(blocks), dim3(256), 0, nullptr, sl.ta[target].mag, T, ctx->tap_tmp);
+        if (hipDeviceSynchronize() != hipSuccess)
+            return -4;
+        src = ctx->tap_tmp;
+    }
     hipError_t e;
     if (rows)
         e = hipMemcpy2D(dst, cols * sizeof(float), src, src_ld * sizeof(float), cols * sizeof(float), rows,

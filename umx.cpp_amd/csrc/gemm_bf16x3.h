@@ -15,7 +15,7 @@
 //     ds_read_b128 / ds_write_b128), double buffered: 2 x 36 KB, two blocks per CU;
 //   * lane l of a wave feeds the MFMA row/column l % 32 with the 8 consecutive k of half l / 32.
 #pragma once
-#include "gemm_kernels.h"
+#include "gemm_common.h"
 
 namespace umx
 {

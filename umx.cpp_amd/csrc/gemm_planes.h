@@ -1,7 +1,6 @@
 // gemm_planes.h -- the dense stack's GEMMs (fc1, W_ih, fc2, fc3: inference.cpp:86,127,143, lstm.cpp:132-135) with BOTH
 // operands arriving as fp16 planes, so that the kernel is nothing but LDS-DMA, fragment reads and matrix-core
-// instructions (the default flavour of track-batched contexts; UMX_GEMM=bf16x3 selects gemm_bf16x3.h, UMX_GEMM=f32
-// gemm_kernels.h).
+// instructions (the default flavour of track-batched contexts; UMX_GEMM=bf16x3 selects gemm_bf16x3.h).
 //
 // What gemm_bf16x3.h spent its time on (the matrix pipe busy 41 %, LDS and VALU next to saturated) was not the
 // products but the staging: every block re-split its 128 x 16 activation tile (44 VALU operations and three 16-byte
@@ -27,7 +26,7 @@
 // (M = lanes x Tp rows); 128 x 128 remains for launches too small to fill the chip with the large tile.  LDS rows are
 // 64 bytes (32 k) as four 16-byte chunks, chunk c of row r stored at chunk c ^ ((r >> 2) & 3): a ds_read_b128 group
 // (16 lanes = rows of 4 residues mod 4 x 4 values of (r >> 2) & 3) then touches every bank exactly once.  STAGES
-// buffers (3 where LDS allows), one barrier per K tile.  Same XCD-aware tile order and epilogues as gemm_kernels.h.
+// buffers (3 where LDS allows), one barrier per K tile.  XCD-aware tile order and epilogues: gemm_common.h.
 #pragma once
 #include "gemm_bf16x3.h"
 #include <cmath>
@@ -41,8 +40,7 @@ struct GemmPTarget
     const unsigned short *A; // planes [2][a_rows][lda] (fp16 bits); plane p at A + p * a_plane
     const unsigned short *B; // planes [NBP][N][K]; plane p at B + p * N * K
     float *C;
-    const float *e0, *e1, *e2, *e3, *q0, *q1, *aux; // as GemmTarget
-    float *dbg;
+    const float *e0, *e1, *e2, *e3, *q0, *q1; // as GemmTarget
     const float *rs0, *rs1; // row sums of A (rs1 optional: second half of a concatenated A)
     const float *rsc;       // per-row inverse scale of A (nullptr: GemmPArgs::a_unscale for every row)
     float bs[2], bo2[2];    // scale, offset + c * scale of the weight tensor(s); columns >= bsplit use [1]
@@ -57,7 +55,7 @@ struct GemmPArgs
     float a_unscale; // inverse of the constant scale of A when t[].rsc == nullptr
     int Tp_lane;    // rows per track lane when M spans several lanes (0: one lane); FC3 epilogue, see GemmArgs
     int lanes;      // track lanes of the launch (M >= lanes * Tp_lane, rounded up to the tile)
-    size_t mag_lane, dbg_lane;
+    size_t mag_lane;
 };
 
 constexpr int GP_BK = 32;
@@ -418,7 +416,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
     GemmTarget et;
     et.C = tg.C;
     et.e0 = tg.e0; et.e1 = tg.e1; et.e2 = tg.e2; et.e3 = tg.e3;
-    et.q0 = tg.q0; et.q1 = tg.q1; et.aux = tg.aux; et.dbg = tg.dbg;
+    et.q0 = tg.q0; et.q1 = tg.q1;
     GemmArgs ea;
     ea.M = args.M;
     ea.ldc = args.ldc;
@@ -426,7 +424,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
     ea.Tp_lane = args.Tp_lane;
     ea.lanes = args.lanes;
     ea.mag_lane = args.mag_lane;
-    ea.dbg_lane = args.dbg_lane;
     gemm_epilogue<MODE>(et, ea, m0, n0, wm, wn, lr, lh, acc00, acc01, acc10, acc11);
 }
 

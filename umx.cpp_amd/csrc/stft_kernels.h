@@ -2,12 +2,12 @@
 //
 // HBM layouts (b fastest, so a wave touches consecutive bins):
 //   spec    float2 [2][T][2049]      (reference: Eigen ColMajor (2,T,2049), c fastest)
-//   mix_mag float  [2][T][2049]
+//   (|X| is not stored: x holds the cropped part the network reads, the Wiener kernels form the rest from spec)
 //   x       float  [Tp][KX]          row t = [ |L|[0:1487] | |R|[0:1487] | 0 0 ]  (inference.cpp:58-68)
 //   y       float2 [4][2][T][2049]   per-source complex spectrograms
 //   frames  float2 [4][T][4096]      (.x = left, .y = right) windowed + normalised iFFT frames
 // Algorithmic HBM bytes per 60 s segment (T = 2584):
-//   stft : read 21.2 MB audio; write 84.7 (spec) + 42.4 (mag) + 30.8 (x) = 157.9 MB
+//   stft : read 21.2 MB audio; write 84.7 (spec) + 30.8 (x) = 115.5 MB
 //   istft: read 338.8 MB (y), write 338.7 MB (frames); ola: read 338.7 MB, write 84.7 MB
 #pragma once
 #include "fft4096.h"
@@ -20,8 +20,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const float *__restrict__ aud
                                                    const float *__restrict__ window,
                                                    const float2 *__restrict__ tw1,
                                                    const float2 *__restrict__ tw2,
-                                                   float2 *__restrict__ spec, float *__restrict__ mix_mag,
-                                                   float *__restrict__ x, unsigned *__restrict__ maxabs_bits)
+                                                   float2 *__restrict__ spec, float *__restrict__ x,
+                                                   unsigned *__restrict__ maxabs_bits)
 {
     __shared__ float2 buf[FFT_LDS_ELEMS];
     __shared__ float red[4];
@@ -56,13 +56,10 @@ __global__ __launch_bounds__(256) void stft_kernel(const float *__restrict__ aud
         const size_t iL = ((size_t)0 * T + f) * NBINS + k, iR = ((size_t)1 * T + f) * NBINS + k;
         spec[iL] = sL;
         spec[iR] = sR;
-        const float mL = hypotf(sL.x, sL.y), mR = hypotf(sR.x, sR.y); // inference.cpp:29 abs()
-        mix_mag[iL] = mL;
-        mix_mag[iR] = mR;
-        if (k < CROP)
-        {
-            x[(size_t)f * KX + k] = mL;
-            x[(size_t)f * KX + CROP + k] = mR;
+        if (k < CROP) // |X| (inference.cpp:29 abs()) is kept only where the network reads it; the Wiener kernels that need
+        {             // it for every bin have the spectrogram in registers anyway and form it again (mix_magnitude, common.h)
+            x[(size_t)f * KX + k] = mix_magnitude(sL);
+            x[(size_t)f * KX + CROP + k] = mix_magnitude(sR);
         }
         // wiener.cpp:37-52 find_max_abs uses sqrt(norm(z))
         lmax = fmaxf(lmax, fmaxf(sqrtf(sL.x * sL.x + sL.y * sL.y), sqrtf(sR.x * sR.x + sR.y * sR.y)));

@@ -4,7 +4,7 @@
 //
 // One workgroup per frame, 1024 threads.
 //   phase 1  thread t handles bins b = t + 1024 q (2049 bins, 2-3 per thread): loads the mixture (2 channels), the four
-//            target magnitudes (x 2 channels) and the four R (16 bytes each), forms what does not depend on the output
+//            targets' masks (x 2 channels; x |X| = the target magnitudes) and the four R (16 bytes each), forms what does not depend on the output
 //            source -- mixture over max_abs, the four PSDs, the inverse of Cxx (wiener.cpp:270-341) -- and then, for each
 //            source, y_s = G_s x (wiener.cpp:343-400), written straight into the INPUT of that source's inverse FFT in
 //            LDS: one complex 4096-point transform per source carries the left channel in its real and the right channel
@@ -54,13 +54,15 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         if (b > NFFT / 2)
             break;
         const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
+        const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
         const float2 X0 = spec[i0], X1 = spec[i1];
+        const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
         float m0[4], m1[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            m0[s] = mags.m[s][i0];
-            m1[s] = mags.m[s][i1];
+            m0[s] = mags.m[s][j0] * h0; // target magnitude = mask x |X| (inference.cpp:175-183)
+            m1[s] = mags.m[s][j1] * h1;
         }
         WienerBin wb;
         float4 rc[4];

@@ -5,13 +5,15 @@
 // F6).  The initial estimate y_j = polar(mag_j, arg X) (wiener.cpp:96-109) is formed as
 // mag_j * X/|X| (phase 0 where X = 0, like std::arg), never materialised in HBM.
 //
-//   pass 1  wiener_stats_kernel   per (source, 200-frame batch, bin): sum_f y y^H and sum_f v, in
-//                                 the reference's batch structure (wiener.cpp:212-258)
-//   pass 2  wiener_finish_kernel  R_j(b) = (sum of batch sums, in batch order) / (eps + sum v)
-//   pass 3  wiener_apply_kernel   per (f, b): Cxx, closed-form 2x2 inverse (wiener.cpp:54-84),
-//                                 gains, y_j = G_j x, * max_abs            -> y [4][2][T][2049]
-// All three are HBM-streaming kernels: algorithmic bytes per 60 s segment
-//   pass 1: 4 x (84.7 spec + 42.4 mag) = 508 MB read;  pass 3: 84.7 + 169.4 read, 338.8 written.
+//   pass 1  wiener_stats4_kernel  per (200-frame batch, bin), all sources: sum_f y y^H and sum_f v, in the reference's
+//                                 batch structure (wiener.cpp:212-258)
+//   pass 2  wiener_finish4_kernel R_j(b) = (sum of batch sums, in batch order) / (eps + sum v)
+//   pass 3  wiener_apply_kernel   per (f, b): Cxx, closed-form 2x2 inverse (wiener.cpp:54-84), gains, y_j = G_j x,
+//                                 * max_abs -> y [4][2][T][2049]   (single-track contexts; track-batched contexts fuse
+//                                 this pass with the inverse STFT: wiener_istft.h)
+// The target magnitudes arrive as MASKS [2][T][MAGP] (gemm_common.h): mag_j = mask_j x |X| (inference.cpp:175-183) is
+// formed here, from the mixture bin that is in registers anyway.
+// (Round 1's per-source statistics kernels -- one frame in flight per thread, the mixture read four times -- are gone.)
 #pragma once
 #include "fft4096.h"
 
@@ -20,7 +22,7 @@ namespace umx
 
 struct WienerMags
 {
-    const float *m[4]; // [2][T][2049] each
+    const float *m[4]; // the four targets' masks, [2][T][MAGP] each
 };
 
 __device__ __forceinline__ float2 unit_phasor(float2 x)
@@ -41,74 +43,6 @@ __device__ __forceinline__ float2 wiener_y0(float mag, float2 x, float max_abs)
     return make_float2((mag * ph.x) / max_abs, (mag * ph.y) / max_abs);
 }
 
-// grid (ceil(B/256), nbatch, 4).  part: [4][nbatch][2049][9] = Re/Im of R00 R01 R10 R11, sum v
-__global__ __launch_bounds__(256) void wiener_stats_kernel(const float2 *__restrict__ spec, WienerMags mags,
-                                                           int T, const unsigned *__restrict__ maxabs_bits,
-                                                           float *__restrict__ part, int nbatch)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x, batch = blockIdx.y, src = blockIdx.z;
-    if (b >= NBINS)
-        return;
-    const float max_abs = wiener_max_abs(maxabs_bits);
-    const float *mag = mags.m[src];
-    const int f0 = batch * WIENER_BATCH, f1 = min(T, f0 + WIENER_BATCH);
-    float2 r[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
-    float wsum = 0.f;
-    for (int f = f0; f < f1; ++f)
-    {
-        const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
-        float2 y[2];
-        y[0] = wiener_y0(mag[i0], spec[i0], max_abs);
-        y[1] = wiener_y0(mag[i1], spec[i1], max_abs);
-        // v = 1/2 sum_c (Re + Im)^2   wiener.cpp:187-202 (F5)
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-        {
-            const float re = y[c].x + y[c].y;
-            sum += (re * re) + (0.f * 0.f);
-        }
-        wsum += sum / 2;
-#pragma unroll
-        for (int c1 = 0; c1 < 2; ++c1)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-            { // calculateCovariance wiener.cpp:435-478: a * conj(b)
-                const float2 a = y[c1], bb = cconj(y[c2]);
-                const float2 pr = cmul(a, bb);
-                r[c1][c2].x += (0.f + pr.x);
-                r[c1][c2].y += (0.f + pr.y);
-            }
-    }
-    float *o = part + (((size_t)src * nbatch + batch) * NBINS + b) * 9;
-    o[0] = r[0][0].x; o[1] = r[0][0].y; o[2] = r[0][1].x; o[3] = r[0][1].y;
-    o[4] = r[1][0].x; o[5] = r[1][0].y; o[6] = r[1][1].x; o[7] = r[1][1].y;
-    o[8] = wsum;
-}
-
-// grid (ceil(B/256), 4).  R: [4][2049][8]
-__global__ __launch_bounds__(256) void wiener_finish_kernel(const float *__restrict__ part, int nbatch,
-                                                            float *__restrict__ R)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
-    if (b >= NBINS)
-        return;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float weight = WIENER_EPS; // wiener.cpp:210
-    for (int k = 0; k < nbatch; ++k)
-    {
-        const float *p = part + (((size_t)src * nbatch + k) * NBINS + b) * 9;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            acc[i] += p[i]; // wiener.cpp:243  R += batch sum
-        weight += p[8];     // wiener.cpp:247-253 (batch partial sums: rounding-order difference only)
-    }
-    float *o = R + ((size_t)src * NBINS + b) * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        o[i] = acc[i] / weight; // wiener.cpp:259-269
-}
-
 // grid (ceil(B/256), T).  y: [4][2][T][2049] complex
 __global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restrict__ spec, WienerMags mags,
                                                            int T, const unsigned *__restrict__ maxabs_bits,
@@ -120,7 +54,9 @@ __global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restr
     const float max_abs = wiener_max_abs(maxabs_bits);
     const float reg = sqrtf(WIENER_EPS); // wiener.cpp:165
     const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
+    const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
     const float2 X0 = spec[i0], X1 = spec[i1];
+    const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
     const float2 x0 = make_float2(X0.x / max_abs, X0.y / max_abs); // wiener.cpp:118-130
     const float2 x1 = make_float2(X1.x / max_abs, X1.y / max_abs);
     float v[4];
@@ -129,8 +65,8 @@ __global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restr
 #pragma unroll
     for (int s = 0; s < 4; ++s)
     {
-        const float2 ya = wiener_y0(mags.m[s][i0], X0, max_abs);
-        const float2 yb = wiener_y0(mags.m[s][i1], X1, max_abs);
+        const float2 ya = wiener_y0(mags.m[s][j0] * h0, X0, max_abs); // inference.cpp:175-183: mask x |X|
+        const float2 yb = wiener_y0(mags.m[s][j1] * h1, X1, max_abs);
         const float ra = ya.x + ya.y, rb = yb.x + yb.y;
         float sum = 0.f;
         sum += (ra * ra) + (0.f * 0.f);
@@ -190,7 +126,7 @@ __global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restr
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Round-2 forms (the three kernels above remain as the unfused reference path, UMX_WIENER=unfused).
+// The statistics pass.
 //
 // R_j is Hermitian BIT FOR BIT: R10 accumulates y1 conj(y0), whose real part is the same two products in the same
 // order as R01's and whose imaginary part is its exact negation; R00 and R11 have an exactly zero imaginary part
@@ -218,13 +154,14 @@ __device__ __forceinline__ void wiener_frame_load(WienerFrame<NS> &w, const floa
                                                   int T, int f, int b)
 {
     const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
+    const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
     w.X0 = spec[i0];
     w.X1 = spec[i1];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
     {
-        w.m0[s] = mag[s][i0];
-        w.m1[s] = mag[s][i1];
+        w.m0[s] = mag[s][j0]; // masks: x |X| in accumulate()
+        w.m1[s] = mag[s][j1];
     }
 }
 
@@ -251,12 +188,14 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
         r00[s] = r01x[s] = r01y[s] = r11[s] = wsum[s] = 0.f;
     auto accumulate = [&](const WienerFrame<NS> &w) {
         const float2 p0 = unit_phasor(w.X0), p1 = unit_phasor(w.X1);
+        const float h0 = mix_magnitude(w.X0), h1 = mix_magnitude(w.X1);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
         {
+            const float t0 = w.m0[s] * h0, t1 = w.m1[s] * h1; // target magnitude = mask x |X| (inference.cpp:175-183)
             // wiener_y0 with the division by max_abs as an exact 3-instruction quotient (div_by, common.h)
-            const float2 y0 = make_float2(div_by(w.m0[s] * p0.x, max_abs, rmax), div_by(w.m0[s] * p0.y, max_abs, rmax));
-            const float2 y1 = make_float2(div_by(w.m1[s] * p1.x, max_abs, rmax), div_by(w.m1[s] * p1.y, max_abs, rmax));
+            const float2 y0 = make_float2(div_by(t0 * p0.x, max_abs, rmax), div_by(t0 * p0.y, max_abs, rmax));
+            const float2 y1 = make_float2(div_by(t1 * p1.x, max_abs, rmax), div_by(t1 * p1.y, max_abs, rmax));
             // v = 1/2 sum_c (Re + Im)^2   wiener.cpp:187-202 (F5)
             const float ra = y0.x + y0.y, rb = y1.x + y1.y;
             float sum = 0.f;
@@ -435,11 +374,14 @@ __global__ __launch_bounds__(256) void mixphase_kernel(const float2 *__restrict_
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n)
         return;
-    const float2 ph = unit_phasor(spec[i]);
+    const float2 X = spec[i];
+    const float2 ph = unit_phasor(X);
+    const float h = mix_magnitude(X);
+    const size_t j = (i / NBINS) * MAGP + i % NBINS; // (c, f) row of the mask planes
 #pragma unroll
     for (int s = 0; s < 4; ++s)
     {
-        const float m = mags.m[s][i];
+        const float m = mags.m[s][j] * h; // inference.cpp:175-183
         y[(size_t)s * n + i] = make_float2(m * ph.x, m * ph.y);
     }
 }
