@@ -204,13 +204,14 @@ def main():
     waves = [np.ascontiguousarray(pkg.ggml.synth_audio(N, seed=rank * 16 + b).T).ravel() for b in range(B)]
     audios = [torch.from_numpy(w).to(dev) for w in waves]
     # two output sets: consecutive steps are in flight together (two pipeline slots) and must not share stems
-    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4 * B)] for _ in range(2)]
+    depth = eng.pipeline_depth()  # that many consecutive steps are in flight together and must not share stems
+    out_sets = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4 * B)] for _ in range(depth)]
     ptr_sets = [[o.data_ptr() for o in st_] for st_ in out_sets]
     aptrs = [a.data_ptr() for a in audios]
     nstep = [0]
 
     def step():
-        eng.infer_batch_ptrs(aptrs, [N] * B, ptr_sets[nstep[0] & 1], flags)
+        eng.infer_batch_ptrs(aptrs, [N] * B, ptr_sets[nstep[0] % depth], flags)
         nstep[0] += 1
         if args.serial:
             eng.sync()
@@ -227,7 +228,7 @@ def main():
     # the duration rocprofv3 reports for the same command); (b) extra steps run one at a time afterwards (each kernel
     # alone on the chip).
     prof_pipelined = eng.lstm_profile() if args.lstm_profile else None
-    st = [d for d in (eng.stage_times(slot=i) for i in (0, 1)) if d]
+    st = [d for d in (eng.stage_times(slot=i) for i in range(depth)) if d]
     stage_ms = {k: sum(d[k] for d in st) / len(st) for k in st[0]} if st else {}
     serial = []
     stage_alone_ms = {}
@@ -245,12 +246,12 @@ def main():
     if not args.no_pcie and world == 1:  # an N = 1 figure, like cpu_baseline (and an exception on one rank must not leave the others at a barrier)
         try:
             h_in = [torch.from_numpy(w).pin_memory() for w in waves]
-            h_out = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4 * B)] for _ in range(2)]
+            h_out = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4 * B)] for _ in range(depth)]
             hp_in, hp_out = [t.data_ptr() for t in h_in], [[t.data_ptr() for t in s] for s in h_out]
             k = [0]
 
             def step_pcie():
-                eng.infer_batch_ptrs(hp_in, [N] * B, hp_out[k[0] & 1], flags, where="host_async")
+                eng.infer_batch_ptrs(hp_in, [N] * B, hp_out[k[0] % depth], flags, where="host_async")
                 k[0] += 1
             dt_pcie = mg.timed_region(step_pcie, fence, args.steps, max(2, args.warmup // 2), dist=dd, world=world, device=dev)
             finite = finite and bool(all(torch.isfinite(o).all().item() for s in h_out for o in s))
@@ -285,19 +286,20 @@ def main():
     if rank == 0 and world == 1 and B > 1 and not args.no_single_track:
         e1 = make_engine(1, False)
         a1 = torch.from_numpy(waves[0]).to(dev)
-        o1 = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)] for _ in range(2)]
+        d1n = e1.pipeline_depth()
+        o1 = [[torch.empty(2 * N, dtype=torch.float32, device=dev) for _ in range(4)] for _ in range(d1n)]
         p1 = [[o.data_ptr() for o in s] for s in o1]
         k1 = [0]
 
         def step1():
-            e1.infer_segment_device(a1.data_ptr(), N, p1[k1[0] & 1], flags)
+            e1.infer_segment_device(a1.data_ptr(), N, p1[k1[0] % d1n], flags)
             k1[0] += 1
 
         def fence1():
             e1.sync()
             torch.cuda.synchronize()
         d1 = mg.timed_region(step1, fence1, 16, 4)
-        s1 = [d for d in (e1.stage_times(slot=i) for i in (0, 1)) if d]
+        s1 = [d for d in (e1.stage_times(slot=i) for i in range(d1n)) if d]
         lstm1 = sum(sum(d[f"lstm_rec{l}"] for l in range(3)) for d in s1) / (3 * len(s1))
         step1()
         e1.sync()
@@ -313,11 +315,11 @@ def main():
         d1p = None
         try:
             h1 = torch.from_numpy(waves[0]).pin_memory()
-            ho1 = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4)] for _ in range(2)]
+            ho1 = [[torch.empty(2 * N, dtype=torch.float32).pin_memory() for _ in range(4)] for _ in range(d1n)]
             kp = [0]
 
             def step1p():
-                e1.infer_batch_ptrs([h1.data_ptr()], [N], [o.data_ptr() for o in ho1[kp[0] & 1]], flags, where="host_async")
+                e1.infer_batch_ptrs([h1.data_ptr()], [N], [o.data_ptr() for o in ho1[kp[0] % d1n]], flags, where="host_async")
                 kp[0] += 1
             d1p = mg.timed_region(step1p, fence1, 16, 4)
         except Exception as e:  # noqa: BLE001

@@ -125,6 +125,10 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                           const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
 int umx_hip_n_tracks(const umx_hip_ctx *ctx);
+/* Segments the context keeps in flight (= its pipeline slots, each with its own stream): 2 (3 with UMX_SLOTS=3 in the
+ * environment: an experiment, see csrc/engine.hip).  The buffers of that many CONSECUTIVE asynchronous calls must be distinct (ordering contract
+ * of umx_hip_infer_segment_device below). */
+int umx_hip_pipeline_depth(const umx_hip_ctx *ctx);
 int umx_hip_lstm_is_batched(const umx_hip_ctx *ctx);
 size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx); /* HBM bytes held by the model's weight matrices */
 void umx_hip_destroy(umx_hip_ctx *ctx);
@@ -147,18 +151,19 @@ int umx_hip_track_stream_set(umx_hip_ctx *ctx, int track, const float *host_src)
  * Host-pointer form: H2D + kernels + D2H, synchronous (umx_inference returns its outputs). */
 int umx_hip_infer_segment(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4],
                           unsigned flags);
-/* The same without the final wait: H2D, kernels and D2H are queued on the stream of the pipeline slot the segment
- * runs in (consecutive calls alternate between two slots).  With PINNED host buffers, and distinct buffers for two
- * consecutive calls, one segment's transfers overlap the other's kernels.  Results are valid after umx_hip_sync.
+/* The same without the final wait: H2D and kernels are queued on the stream of the pipeline slot the segment runs in
+ * (consecutive calls go round the slots), the D2H on a copy stream behind them.  With PINNED host buffers, and distinct
+ * buffers for umx_hip_pipeline_depth() consecutive calls, one segment's transfers overlap the others' kernels.  Results
+ * are valid after umx_hip_sync.
  * BUFFER CONTRACT: audio_host and out_host of every call queued since the last umx_hip_sync must stay valid and
  * unchanged until that sync returns -- the timeout recovery described there uploads the audio again. */
 int umx_hip_infer_segment_async(umx_hip_ctx *ctx, const float *audio_host, int n, float *const out_host[4],
                                 unsigned flags);
 /* Device-pointer form: buffers already in HBM (audio 2*n floats, out[t] 2*n floats each); asynchronous.
- * ORDERING CONTRACT: consecutive calls are queued on two alternating internal streams (the cross-segment
- * pipeline), so (1) audio_dev and out_dev must stay untouched by the caller until umx_hip_sync -- or until the
- * caller's stream has been ordered behind the engine with umx_hip_order_before; (2) two CONSECUTIVE calls must be
- * given DISTINCT out_dev buffers (both segments are in flight together); (3) work the caller queued on a stream
+ * ORDERING CONTRACT: consecutive calls are queued round-robin on umx_hip_pipeline_depth() internal streams (the
+ * cross-segment pipeline), so (1) audio_dev and out_dev must stay untouched by the caller until umx_hip_sync -- or until
+ * the caller's stream has been ordered behind the engine with umx_hip_order_before; (2) umx_hip_pipeline_depth()
+ * CONSECUTIVE calls must be given DISTINCT out_dev buffers (that many segments are in flight together); (3) work the caller queued on a stream
  * of its own that produces audio_dev is ordered in front of the next call with umx_hip_order_after.
  * A caller that fences with umx_hip_order_before (and then recycles its buffers) gives up the timeout recovery for the
  * calls queued so far: a persistent-kernel timeout among them is reported as UMX_ERR_TIMEOUT by the next umx_hip_sync. */

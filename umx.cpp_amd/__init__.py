@@ -80,6 +80,7 @@ def hip_lib():
     lib.umx_hip_create_tracks.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(TensorView), C.c_int,
                                           C.c_uint, C.c_int]
     lib.umx_hip_n_tracks.argtypes = [C.c_void_p]
+    lib.umx_hip_pipeline_depth.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_is_batched.argtypes = [C.c_void_p]
     lib.umx_hip_debug_f16_bits.argtypes = [C.c_float]
     lib.umx_hip_debug_f16_bits.restype = C.c_uint
@@ -157,7 +158,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
                "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits",
-               "umx_hip_segment_masks_device", "umx_hip_target_mag_device", "umx_hip_segment_finish_device", "umx_hip_gate_reserve", "umx_hip_segment_discard"]
+               "umx_hip_segment_masks_device", "umx_hip_target_mag_device", "umx_hip_segment_finish_device", "umx_hip_gate_reserve", "umx_hip_segment_discard", "umx_hip_pipeline_depth"]
 
 
 def views_from_file_tensors(targets, quantised=True):
@@ -227,6 +228,10 @@ class Engine:
 
     def lstm_is_batched(self):
         return bool(self.lib.umx_hip_lstm_is_batched(self.h))
+
+    def pipeline_depth(self):
+        """Segments in flight together: that many consecutive asynchronous calls need distinct buffers."""
+        return int(self.lib.umx_hip_pipeline_depth(self.h))
 
     def weight_bytes(self):
         return int(self.lib.umx_hip_weight_bytes(self.h))

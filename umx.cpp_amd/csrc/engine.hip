@@ -144,10 +144,15 @@ struct Slot
 } // namespace
 
 // Admission of persistent LSTM grids, process-wide and per device.  A persistent launch needs ALL its workgroups
-// co-resident (they exchange granules), so two such grids may only be in flight together if both fit the device.
-// Inside one context the pipeline orders its own launches with events; this gate does the same ACROSS contexts
-// (several engines on one GPU, driven from several threads): a launch that would not fit is made to wait -- on the
-// device, through a stream-wait on the oldest admitted grid's completion event, never by blocking the host.
+// co-resident (they exchange granules), so the grids that can be resident TOGETHER must fit the device together.
+// Grids queued on one stream run one after the other, so a stream contributes at most its largest queued grid; what has
+// to fit is the sum over streams.  A launch that would not fit is made to wait -- on the device, through a stream-wait
+// on another stream's newest admitted grid (which, streams being in order, is a wait for all of that stream's grids),
+// never by blocking the host -- for the streams whose queued grids are oldest, until it fits.  The streams it waits for
+// hold only grids admitted earlier, i.e. work that does not depend on the new launch: no cycle.
+// (Rounds 1-2 summed over all queued grids instead of over streams: with the host running ahead of the device, a launch then
+// waited for every earlier grid but the most recent one, and the two-slot wavefront of a single-track context overlapped
+// only L2(s) with L0(s+1) -- one pair per segment instead of every layer.  Found in round 3.)
 // Units are half CUs: a single-track workgroup (two fit a CU) counts 1, a batched one (one per CU) counts 2.
 namespace
 {
@@ -158,9 +163,12 @@ struct LstmGate
     {
         hipEvent_t done;
         int units;
+        hipStream_t stream;
+        unsigned long long seq;
     };
-    std::vector<Grid> inflight;
+    std::vector<Grid> inflight; // in admission order
     std::vector<hipEvent_t> pool;
+    unsigned long long seq = 0;
     int reserved = 0; // half CUs kept free for kernels that are not this engine's (RCCL send / recv: umx_hip_gate_reserve)
 };
 LstmGate g_gate[16];
@@ -171,7 +179,6 @@ template <class Launch> hipError_t lstm_gate_launch(int device, hipStream_t st, 
     LstmGate &g = g_gate[device & 15];
     std::lock_guard<std::mutex> lock(g.m);
     capacity_units -= g.reserved;
-    int used = 0;
     for (size_t i = 0; i < g.inflight.size();)
         if (hipEventQuery(g.inflight[i].done) == hipSuccess)
         {
@@ -179,12 +186,45 @@ template <class Launch> hipError_t lstm_gate_launch(int device, hipStream_t st, 
             g.inflight.erase(g.inflight.begin() + i);
         }
         else
-            used += g.inflight[i++].units;
+            ++i;
     (void)hipGetLastError(); // hipEventQuery reports "not ready" as an error
-    for (size_t i = 0; i < g.inflight.size() && used + units > capacity_units; ++i)
+    // per other stream: its largest queued grid, the admission number of its oldest one, and its newest grid's event
+    struct PerStream
     {
-        (void)hipStreamWaitEvent(st, g.inflight[i].done, 0); // oldest first; it has left the device when we start
-        used -= g.inflight[i].units;
+        hipStream_t stream;
+        int units;
+        unsigned long long oldest;
+        hipEvent_t newest;
+    };
+    std::vector<PerStream> others;
+    for (const LstmGate::Grid &gr : g.inflight)
+    {
+        if (gr.stream == st)
+            continue;
+        PerStream *ps = nullptr;
+        for (PerStream &o : others)
+            if (o.stream == gr.stream)
+                ps = &o;
+        if (!ps)
+        {
+            others.push_back({gr.stream, 0, gr.seq, gr.done});
+            ps = &others.back();
+        }
+        ps->units = std::max(ps->units, gr.units);
+        ps->newest = gr.done; // admission order: the last one seen is the newest
+    }
+    int used = 0;
+    for (const PerStream &o : others)
+        used += o.units;
+    while (used + units > capacity_units && !others.empty())
+    {
+        size_t k = 0;
+        for (size_t i = 1; i < others.size(); ++i)
+            if (others[i].oldest < others[k].oldest)
+                k = i;
+        (void)hipStreamWaitEvent(st, others[k].newest, 0); // every grid of that stream has left the device when we start
+        used -= others[k].units;
+        others.erase(others.begin() + k);
     }
     hipEvent_t ev = nullptr;
     if (!g.pool.empty())
@@ -196,7 +236,7 @@ template <class Launch> hipError_t lstm_gate_launch(int device, hipStream_t st, 
         ev = nullptr;
     const hipError_t e = launch();
     if (ev && e == hipSuccess && hipEventRecord(ev, st) == hipSuccess)
-        g.inflight.push_back({ev, units});
+        g.inflight.push_back({ev, units, st, g.seq++});
     else if (ev)
         g.pool.push_back(ev);
     return e;
@@ -260,7 +300,8 @@ struct umx_hip_ctx
     float2 *tw1 = nullptr, *tw2 = nullptr;
     float *tap_tmp = nullptr;                    // umx_hip_read_tap: scratch of the computed taps
     float *audio_in = nullptr, *out_dev[4] = {}; // device staging of the phased (multi-GPU carry) entry points
-    float *stage_in[2] = {}, *stage_out[2][4 * LSTMB_MAX_TRACKS] = {}; // per pipeline slot: device staging of the host-pointer
+    static constexpr int kMaxSlots = 3;
+    float *stage_in[kMaxSlots] = {}, *stage_out[kMaxSlots][4 * LSTMB_MAX_TRACKS] = {}; // per pipeline slot: device staging of the host-pointer
     int ensure_staging();                                              // entry points, [lane] / [lane][4]; allocated on first use
     hipEvent_t order_ev = nullptr;
     struct DeferredDownload // the stems of the most recent host-pointer call, still in its slot's staging buffers
@@ -273,8 +314,14 @@ struct umx_hip_ctx
     int flush_deferred();
     hipStream_t copy_stream = nullptr; // downloads of the host-pointer calls (created with the staging buffers)
     float *state = nullptr;
-    Slot slot[2];
-    int nslots = 2;
+    Slot slot[kMaxSlots];
+    int nslots = 2; // pipeline slots: 3 for single-track contexts (see init), 2 for track-batched ones
+    int next_slot() const { return (int)(nseg % nslots); }
+    void clear_used()
+    {
+        for (int si = 0; si < kMaxSlots; ++si)
+            slot[si].used = false;
+    }
     int B = 1;                // track lanes (umx_hip_create_tracks); every lane has its own streaming LSTM state
     bool lstm_batched = false; // LSTM recurrence on the matrix cores for all lanes at once (lstm_batch.h); fixed at
                                // create so that a track's bits never depend on how many lanes a call uses
@@ -366,11 +413,11 @@ struct umx_hip_ctx
                     unsigned flags, void (*progress)(float, void *), void *progress_user);
     struct TrackBufs // whole-track driver, per track lane: the (shifted) track, 4 stem accumulators, weight sum, 2 x 4 segment stems
     {
-        float *in = nullptr, *out[4] = {}, *sumw = nullptr, *seg[2][4] = {};
+        float *in = nullptr, *out[4] = {}, *sumw = nullptr, *seg[kMaxSlots][4] = {};
         size_t cap = 0;
     };
     std::vector<TrackBufs> trk;
-    hipEvent_t trk_acc_ev[2] = {};
+    hipEvent_t trk_acc_ev[kMaxSlots] = {};
     int phase_begin(const float *audio_host, int n, unsigned flags);
     int phase_begin_device(const float *audio_dev, int n, unsigned flags);
     int phase_end_device(float *const out_dev_[4]);
@@ -1003,7 +1050,13 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) * ((B + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS) : (size_t)0);
     if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
         lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
+    // Two slots.  (Three were tried for single-track contexts in round 3 -- a third segment in flight has its front stage
+    // done by the time an LSTM grid retires, so that two grids would be resident all the time: 7.57 ms per segment against
+    // 6.70 with two; the grids and the GEMM blocks beside them only slow each other down, avg LSTM launch 3.03 -> 3.79 ms.
+    // UMX_SLOTS=3 keeps the experiment available.)
     nslots = 2;
+    if (const char *e = getenv("UMX_SLOTS"))
+        nslots = std::min(std::max(atoi(e), 2), (int)kMaxSlots);
     for (int si = 0; si < nslots; ++si)
     {
         Slot &sl = slot[si];
@@ -1204,7 +1257,7 @@ int umx_hip_ctx::ensure_staging()
     if (stage_in[0])
         return UMX_OK;
     UMX_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    for (int si = 0; si < 2; ++si)
+    for (int si = 0; si < nslots; ++si)
     {
         for (hipEvent_t *e : {&slot[si].k_done, &slot[si].out_free})
             UMX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -1865,9 +1918,9 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
     // Consecutive calls alternate between two slots/streams; a slot is reused two calls later (stream order
     // protects its buffers).  Everything that touches the streaming LSTM state is ordered by events: R_l of
     // this segment waits for R_l of the previous one.
-    const int si = (int)(nseg & 1);
+    const int si = next_slot();
     Slot &sl = slot[si];
-    Slot &prev = slot[si ^ 1];
+    Slot &prev = slot[(si + nslots - 1) % nslots];
     hipStream_t st = sl.stream;
     int active[4], nact;
     active_list(flags, active, nact);
@@ -2024,19 +2077,19 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
             tb_.cap = cap;
         }
         if (!tb_.seg[0][0])
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < nslots; ++s)
                 for (int t = 0; t < 4; ++t)
                     if (int rc = dalloc(&tb_.seg[s][t], (size_t)2 * N, false))
                         return rc;
     }
     if (!trk_acc_ev[0])
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < nslots; ++s)
             UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
     const bool timing = getenv("UMX_TRACK_TIMING") != nullptr;
     const auto tt0 = std::chrono::steady_clock::now();
     // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
     UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats() * nt));
-    slot[0].used = slot[1].used = false;
+    clear_used();
     for (int ln = 0; ln < nt; ++ln)
     {
         TrackBufs &tb_ = trk[ln];
@@ -2069,7 +2122,7 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
     for (long long off = 0; off < L2max; off += stride, ++iseg)
     {
         const int offset = (int)off;
-        const int si = (int)(nseg & 1);
+        const int si = next_slot();
         const float *ain[LSTMB_MAX_TRACKS] = {};
         int nn[LSTMB_MAX_TRACKS] = {};
         float *outs[4 * LSTMB_MAX_TRACKS] = {};
@@ -2231,7 +2284,7 @@ int umx_hip_ctx::phase_end_device(float *const out_dev_[4])
     if (int rc = stage_back(sl, sl.stream, 1, &ain, out_dev_, &ph_n, ph_flags, active, nact))
         return rc;
     cur = 0;
-    slot[0].used = slot[1].used = false;
+    clear_used();
     return UMX_OK;
 }
 
@@ -2269,7 +2322,7 @@ int umx_hip_ctx::phase_finish_device(float *const out_dev_[4])
     if (int rc = stage_finish(sl, sl.stream, 1, &ain, out_dev_, &ph_n, ph_flags, false))
         return rc;
     cur = 0;
-    slot[0].used = slot[1].used = false;
+    clear_used();
     return UMX_OK;
 }
 
@@ -2322,7 +2375,7 @@ int umx_hip_ctx::phase_end(float *const out_host[4])
         return rc;
     for (int s = 0; s < 4; ++s)
         UMX_HIP_CHECK(hipMemcpy(out_host[s], out_dev[s], sizeof(float) * 2 * (size_t)ph_n, hipMemcpyDeviceToHost));
-    slot[0].used = slot[1].used = false; // drained: nothing for the next segment to wait for
+    clear_used(); // drained: nothing for the next segment to wait for
     return UMX_OK;
 }
 
@@ -2390,7 +2443,7 @@ int umx_hip_ctx::recover()
     for (int l = 0; l < 3; ++l) // layer l of every (lane, target): 4 * Hl floats every 12 * Hl
         UMX_HIP_CHECK(hipMemcpy2D(state + (size_t)l * 4 * Hl, sizeof(float) * 12 * Hl, backup + (size_t)l * per * B + (size_t)l * 4 * Hl,
                                   sizeof(float) * 12 * Hl, sizeof(float) * 4 * Hl, (size_t)B * 4, hipMemcpyDeviceToDevice));
-    slot[0].used = slot[1].used = false;
+    clear_used();
     recovering = true;
     int rc = UMX_OK;
     for (const PendingCall &pc : calls)
@@ -2401,7 +2454,7 @@ int umx_hip_ctx::recover()
         for (int ln = 0; ln < pc.nb; ++ln)
             if (pc.host_audio[ln] && pc.audio[ln])
                 UMX_HIP_CHECK(hipMemcpyAsync(const_cast<float *>(pc.audio[ln]), pc.host_audio[ln], sizeof(float) * 2 * (size_t)pc.n[ln],
-                                             hipMemcpyHostToDevice, slot[nseg & 1].stream));
+                                             hipMemcpyHostToDevice, slot[next_slot()].stream));
         if ((rc = infer_batch(pc.nb, pc.audio, pc.n, pc.out, (pc.flags | UMX_FLAG_LSTM_STEPWISE) & ~UMX_FLAG_DEBUG_LSTM_ABORT)) != UMX_OK)
             break;
         for (int k = 0; k < 4 * pc.nb; ++k) // the host-pointer forms had copied the failed run's stems out
@@ -2476,6 +2529,7 @@ int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int se
 }
 
 int umx_hip_n_tracks(const umx_hip_ctx *ctx) { return ctx ? ctx->B : 0; }
+int umx_hip_pipeline_depth(const umx_hip_ctx *ctx) { return ctx ? ctx->nslots : 0; }
 int umx_hip_lstm_is_batched(const umx_hip_ctx *ctx) { return ctx && ctx->lstm_batched ? 1 : 0; }
 
 unsigned umx_hip_debug_f16_bits(float x) { return f16_rne_bits(x); }
@@ -2495,11 +2549,11 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
         (void)hipEventDestroy(ctx->order_ev);
     if (ctx->copy_stream)
         (void)hipStreamDestroy(ctx->copy_stream);
-    for (int si = 0; si < 2; ++si)
+    for (int si = 0; si < umx_hip_ctx::kMaxSlots; ++si)
         for (hipEvent_t e : {ctx->slot[si].k_done, ctx->slot[si].out_free})
             if (e)
                 (void)hipEventDestroy(e);
-    for (int si = 0; si < 2; ++si)
+    for (int si = 0; si < umx_hip_ctx::kMaxSlots; ++si)
     {
         Slot &sl = ctx->slot[si];
         for (int i = 0; i <= ST_COUNT; ++i)
@@ -2535,7 +2589,7 @@ int umx_hip_track_stream_reset(umx_hip_ctx *ctx, int track)
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
-    ctx->slot[0].used = ctx->slot[1].used = false; // nothing in flight: no cross-segment dependency to wait for
+    ctx->clear_used(); // nothing in flight: no cross-segment dependency to wait for
     return UMX_OK;
 }
 int umx_hip_stream_reset(umx_hip_ctx *ctx) { return umx_hip_track_stream_reset(ctx, 0); }
@@ -2570,7 +2624,7 @@ int umx_hip_track_stream_set(umx_hip_ctx *ctx, int track, const float *host_src)
         ctx->set_error(hipGetErrorString(e));
         return UMX_ERR_HIP;
     }
-    ctx->slot[0].used = ctx->slot[1].used = false;
+    ctx->clear_used();
     return UMX_OK;
 }
 int umx_hip_stream_set(umx_hip_ctx *ctx, const float *host_src) { return umx_hip_track_stream_set(ctx, 0, host_src); }
@@ -2672,7 +2726,7 @@ int umx_hip_segment_discard(umx_hip_ctx *ctx)
         return UMX_ERR_ARG;
     ctx->ph_next = -1; // whatever was queued runs to its end; the next segment may begin
     ctx->cur = 0;
-    ctx->slot[0].used = ctx->slot[1].used = false;
+    ctx->clear_used();
     return UMX_OK;
 }
 int umx_hip_segment_finish_device(umx_hip_ctx *ctx, float *const out_dev[4]) { return ctx ? ctx->phase_finish_device(out_dev) : UMX_ERR_ARG; }
@@ -2755,7 +2809,7 @@ int umx_hip_order_after(umx_hip_ctx *ctx, void *hip_stream)
         e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipEventRecord(ctx->order_ev, (hipStream_t)hip_stream);
-    for (int si = 0; si < 2 && e == hipSuccess; ++si)
+    for (int si = 0; si < ctx->nslots && e == hipSuccess; ++si)
         e = hipStreamWaitEvent(ctx->slot[si].stream, ctx->order_ev, 0);
     if (e != hipSuccess)
     {
@@ -2779,7 +2833,7 @@ int umx_hip_order_before(umx_hip_ctx *ctx, void *hip_stream)
     hipError_t e = hipSuccess;
     if (!ctx->order_ev)
         e = hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming);
-    for (int si = 0; si < 2 && e == hipSuccess; ++si)
+    for (int si = 0; si < ctx->nslots && e == hipSuccess; ++si)
     {
         e = hipEventRecord(ctx->order_ev, ctx->slot[si].stream);
         if (e == hipSuccess)
@@ -2832,7 +2886,7 @@ int umx_hip_sync(umx_hip_ctx *ctx)
             }
             // no way back: the aborted launch left a mix of updated and stale chains behind
             (void)hipMemset(ctx->state, 0, sizeof(float) * ctx->state_floats() * ctx->B);
-            ctx->slot[0].used = ctx->slot[1].used = false;
+            ctx->clear_used();
             ctx->pending.clear();
             ctx->pending_lost = false;
             ctx->set_error(what + "; the streaming LSTM state was reset to zero, later segments run the per-step driver");
@@ -2855,7 +2909,7 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
             ctx->set_error("infer: bad arguments");
         return UMX_ERR_ARG;
     }
-    const int si = (int)(ctx->nseg & 1);
+    const int si = ctx->next_slot();
     if (int rc = ctx->ensure_staging())
         return rc;
     Slot &sl = ctx->slot[si];
@@ -3040,7 +3094,7 @@ int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap
 
 int umx_hip_stage_times_slot(umx_hip_ctx *ctx, int slot_index, const char **names, float *ms, int cap)
 {
-    if (!ctx || slot_index < 0 || slot_index > 1)
+    if (!ctx || slot_index < 0 || slot_index >= ctx->nslots)
         return 0;
     Slot &sl = ctx->slot[slot_index];
     if (!sl.have_times || ctx->sync_all() != UMX_OK)
