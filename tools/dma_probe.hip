@@ -51,6 +51,69 @@ template <int FULL> __global__ __launch_bounds__(1024) void probe(const unsigned
         *sink = acc;
 }
 
+// ---- the same sweep with the source coming from HBM (4 GiB, read once): rows as they lie in a row-major plane (every
+// wave-instruction takes 64 bytes out of 16 different rows, 5952 or 2048 bytes apart) against a K-tiled plane, where the 256
+// rows x 64 bytes of one (row band, K step) are one contiguous 16 KiB block (a wave-instruction = 1 KiB contiguous)
+template <int TILED> __global__ __launch_bounds__(1024) void probe_hbm(const unsigned short *src, int row_bytes, int bands_per_wg, unsigned *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(src), 0, 0xffffffff, 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    const int voff = TILED ? lane * 16 : (lane >> 2) * row_bytes + (lane & 3) * 16;
+    unsigned acc = 0;
+    for (int b = 0; b < bands_per_wg; ++b)
+    {
+        const long band = ((long)blockIdx.x * bands_per_wg + b) * 256 * row_bytes;
+        for (int k0 = 0; k0 < row_bytes; k0 += 64)
+        {
+            const int buf = ((k0 >> 6) % 3) * 16384;
+            // 16 groups of 16 rows, one per wave
+            const long off = TILED ? band + (long)(k0 >> 6) * 16384 + wave * 1024 : band + (long)wave * 16 * row_bytes + k0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(size_t)(lds0 + buf + wave * 1024), 16, voff, (int)(off & 0x7fffffff) + (int)0, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0x0f70 | 2); // two stages in flight
+            acc += smem[(lane * 16 + k0) & 32767];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (acc == 0x12345678u)
+        *sink = acc;
+}
+
+static void hbm_runs(unsigned *sink)
+{
+    for (int row_bytes : {2048, 5952})
+    {
+        const size_t total = (size_t)1 << 31; // 2 GiB per launch (the buffer resource addresses 2^31 bytes), source never re-read
+        const int bands = (int)(total / ((size_t)256 * row_bytes)), per_wg = bands / 256;
+        unsigned short *src;
+        hipMalloc(&src, total);
+        hipMemset(src, 1, total);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(probe_hbm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(probe_hbm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int tiled = 0; tiled < 2; ++tiled)
+            for (int it = 0; it < 2; ++it)
+            {
+                hipEventRecord(e0);
+                if (tiled)
+                    hipLaunchKernelGGL(probe_hbm<1>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, per_wg, sink);
+                else
+                    hipLaunchKernelGGL(probe_hbm<0>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, per_wg, sink);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                printf("from HBM, rows of %d B, %s: %.3f ms, %.2f TB/s into LDS\n", row_bytes,
+                       tiled ? "K-tiled plane (1 KiB contiguous per wave-instruction)" : "row-major plane (16 rows x 64 B per wave-instruction)", ms,
+                       (double)per_wg * 256 * 256 * row_bytes / (ms * 1e-3) / 1e12);
+            }
+        hipFree(src);
+    }
+}
+
 int main()
 {
     const int row_bytes = 2048, rows = 256 * 256, reps = 8; // 128 MiB source: L2 + MALL resident after the first sweep
@@ -79,5 +142,6 @@ int main()
             printf("%s lines: %.3f ms, %.2f TB/s into LDS\n", full ? "full (8 rows x 128 B)" : "half (16 rows x 64 B)", ms,
                    (double)rows * row_bytes * reps / (ms * 1e-3) / 1e12);
         }
+    hbm_runs(sink);
     return 0;
 }

@@ -17,6 +17,14 @@
 // kernel, group or lane it runs in (tests/test_gpu_batch.py).
 // u8-resident W_hh only (one fp16 plane of q - 128 against two fp16 planes of h * 2^14); other weight forms run the
 // 16-lane kernel once per group.
+//
+// Tried and measured in round 3, none of it faster than this form: requesting the NEXT turn's granules half a
+// turn ahead, between the two halves of the current group's matrix instructions, so that the poll's L2 round trip would be
+// off the turn (8.8 -> 10.7 ms per 32-lane launch, 12.8 -> 14.1 ms for 48 lanes: the granules of the slowest of the chain's
+// 32 workgroups are not there yet, and a failed first attempt costs a second round trip; round 2 saw the same a whole turn
+// ahead); sum_k h' from pair sums carried in the granules' free dword instead of the all-ones tile (LSTMB_HSUM_GRANULE:
+// matrix-pipe cycles -20 %, time +1.5 %: two dependent lane exchanges cost more than four queued matrix instructions).
+// Kept: the W_ih-row ring at a pitch of 272 bytes (SQ_LDS_BANK_CONFLICT 1.5e8 -> 2e7 per launch; same time).
 #pragma once
 #include "lstm_batch.h"
 
@@ -26,7 +34,7 @@ namespace umx
 constexpr int LSTMB2_THREADS = 768;
 __host__ __device__ inline size_t lstmb2_lds_bytes(int groups, int bulk)
 {
-    return (size_t)groups * 8 * 16 * 16 * 16 /* part */ + (size_t)groups * 2 * bulk * 16 * 256 /* rings */;
+    return (size_t)groups * 8 * 16 * 16 * 16 /* part */ + (size_t)groups * 2 * bulk * 16 * LSTMB_RING_PITCH /* rings */;
 }
 
 template <int HL, int G, bool FAST, bool PRECISE>
@@ -41,7 +49,7 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
     const int gw = w - 8; // gate wave gw finishes M tile gw (units 4 gw .. 4 gw + 3 of the slice)
 
     float4 *part = reinterpret_cast<float4 *>(smem);                                // [G][8 waves][4 tiles][4 q][16]
-    float *ring = reinterpret_cast<float *>(smem + (size_t)G * 8 * 16 * NB * 16);   // [G][2*bulk rows][16][64]
+    unsigned char *ring = smem + (size_t)G * 8 * 16 * NB * 16;                      // [G][2*bulk rows][16] blocks of 64 floats, LSTMB_RING_PITCH apart
 
     // ---- W_hh fragments (as lstm_batch.h, WQ form): lane (i = l & 15, q) of tile mt holds gate column 16 mt + i
     f16x8 Wf[4][KSW];
@@ -104,7 +112,7 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
             const int g = i / (bulk * NB), r = first_row + (i % (bulk * NB)) / NB, nn = i % NB, ln = NB * g + nn;
             if (r < t_end && ((lane_mask >> ln) & 1ull))
                 __builtin_amdgcn_global_load_lds((glb_ptr)(Pp + (size_t)ln * p_stride + (size_t)(dir == 0 ? r : T - 1 - r) * ldp),
-                                                 (lds_ptr)(size_t)(ring_lds + 256u * (unsigned)(((g * 2 * bulk + (r & ring_mask)) * NB) + nn)), 4, 0, 0);
+                                                 (lds_ptr)(size_t)(ring_lds + (unsigned)LSTMB_RING_PITCH * (unsigned)(((g * 2 * bulk + (r & ring_mask)) * NB) + nn)), 4, 0, 0);
         }
     };
     if (dot_wave)
@@ -128,6 +136,9 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
             if (dot_wave)
             {
                 f16x8 hf[KSW][2];
+#if LSTMB_HSUM_GRANULE
+                float sumh = 0.f; // this lane's share of sum_k h'_k (lstm_batch.h: pair sums travel in the granules)
+#endif
                 if (step == t_begin)
                 {
                     // h_{t_begin - 1} from the fp32 stream state, split like a published granule
@@ -140,6 +151,9 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                             hv[j] = lane_on[g] ? a.state[st_h[g] + (w * KSW + ks) * 32 + 8 * q + j] : 0.f;
                         uint4 p1, p2;
                         split2_f16(hv, HSCALE, p1, p2);
+#if LSTMB_HSUM_GRANULE
+                        sumh += planes_hsum(p1, p2);
+#endif
                         hf[ks][0] = __builtin_bit_cast(f16x8, p1);
                         hf[ks][1] = __builtin_bit_cast(f16x8, p2);
                     }
@@ -192,6 +206,9 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                                     g3 = lane_on[g] ? v[ks][3] : z;
                         hf[ks][0] = __builtin_bit_cast(f16x8, make_uint4(g0.y, g1.y, g2.y, g3.y));
                         hf[ks][1] = __builtin_bit_cast(f16x8, make_uint4(g0.z, g1.z, g2.z, g3.z));
+#if LSTMB_HSUM_GRANULE
+                        sumh += ((__uint_as_float(g0.w) + __uint_as_float(g1.w)) + __uint_as_float(g2.w)) + __uint_as_float(g3.w);
+#endif
                     }
                     // ring rows <= step - 2 may be replaced (every gate wave has read row step - 1 before the barriers of
                     // step - 1): rows [step-1+bulk, step-1+2 bulk) take the slots of [step-1-bulk, step-1); first read
@@ -210,13 +227,17 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
                             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[mt][ks], hf[ks][ph], acc[mt], 0, 0, 0);
+#if LSTMB_HSUM_GRANULE
+                const float hs = wof2 * fold_q(sumh);
+#else
 #pragma unroll
                 for (int ph = 1; ph >= 0; --ph)
 #pragma unroll
                     for (int ks = 0; ks < KSW; ++ks)
                         accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, hf[ks][ph], accH, 0, 0, 0);
-                float4 *pw = part + ((size_t)((g * 8 + w) * 4) * 4 + q) * NB + n;
                 const float hs = wof2 * accH[0];
+#endif
+                float4 *pw = part + ((size_t)((g * 8 + w) * 4) * 4 + q) * NB + n;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     pw[(size_t)mt * 4 * NB] = make_float4(wsc * acc[mt][0] + hs, wsc * acc[mt][1] + hs, wsc * acc[mt][2] + hs, wsc * acc[mt][3] + hs);
@@ -226,7 +247,7 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                 outp[(size_t)(NB * g) * a.out_stride + (size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast[g]; // lstm.cpp:163-164,170-171
             float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gate_wave)
-                p4 = *reinterpret_cast<const float4 *>(ring + ((size_t)((g * 2 * bulk + (step & ring_mask)) * NB + n)) * 64 + 4 * (4 * gw + q));
+                p4 = *reinterpret_cast<const float4 *>(ring + (size_t)((g * 2 * bulk + (step & ring_mask)) * NB + n) * LSTMB_RING_PITCH + 16 * (4 * gw + q));
             __syncthreads();
             if (*abort_flag)
                 return;
@@ -272,7 +293,8 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                     hlast[g] = h;
                     if ((q & 1) == 0) // publish the pair (this unit, the next), tagged step + 1
                     {
-                        const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u), 0u);
+                        const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u),
+                                                    LSTMB_HSUM_GRANULE ? __float_as_uint(pair_hsum(mine12, other12)) : 0u);
                         granule_store16<FAST>(gran_rs, (int)(g * group_bytes + lstmb_granule_index(step & 1, chain, unit, n, HL, NB) * 16), gv);
                     }
                 }
