@@ -304,14 +304,13 @@ struct umx_hip_ctx
     float *stage_in[kMaxSlots] = {}, *stage_out[kMaxSlots][4 * LSTMB_MAX_TRACKS] = {}; // per pipeline slot: device staging of the host-pointer
     int ensure_staging();                                              // entry points, [lane] / [lane][4]; allocated on first use
     hipEvent_t order_ev = nullptr;
-    struct DeferredDownload // the stems of the most recent host-pointer call, still in its slot's staging buffers
+    struct DeferredDownload // the stems of a host-pointer call, in its slot's staging buffers
     {
         bool valid = false;
         int si = 0, nb = 0, n[LSTMB_MAX_TRACKS] = {};
         float *host[4 * LSTMB_MAX_TRACKS] = {};
-    } deferred;
+    };
     int queue_download(const DeferredDownload &d, hipStream_t on); // D2H copies of d onto stream `on`, then out_free of its slot
-    int flush_deferred();
     hipStream_t copy_stream = nullptr; // downloads of the host-pointer calls (created with the staging buffers)
     float *state = nullptr;
     Slot slot[kMaxSlots];
@@ -1270,26 +1269,22 @@ int umx_hip_ctx::ensure_staging()
     return UMX_OK;
 }
 
-// Host-pointer calls: where the stems of call k go out.  On the slot's own stream right behind its kernels, the download
-// (48 ms for 32 lanes) stands in front of call k + 2's upload and kernels; the two slots then fall into lock step -- kernels
-// of two calls, downloads of two calls, uploads of two calls, nothing overlapping (measured with the kernel + copy trace,
-// round 3: 128 ms per step against 80 ms of kernels).  On a copy stream of its own the runtime turns the download into
-// shader blits that queue behind the persistent LSTM grids (worse: 141 ms).  So it is queued on the OTHER slot's stream
-// behind call k + 1's kernels: it then runs (on the DMA engines) beside call k + 2's kernels, whose overlap-add waits for
-// `out_free` before it reuses the staging buffers; the last call's download is queued by whoever synchronises.
-__global__ void copy_stream_marker_kernel() {}
-
+// Host-pointer calls: where the stems of call k go out (round 3; kernel + copy timelines by tools/pcie_trace.sh).
+//   * On the slot's own stream right behind its kernels (rounds 1-2), the download (48 ms for 32 lanes) stands in front of
+//     call k + 2's upload and kernels; the two slots then fall into lock step -- kernels of two calls, downloads of two
+//     calls, uploads of two calls, nothing overlapping: 128 ms per step against 78 ms of kernels.
+//   * On the slot's own stream one call LATER (behind call k + 2's front stage): the same 129 ms.
+//   * On the OTHER slot's stream behind call k + 1's kernels: 110-113 ms (the copies stay on the DMA engines, but a call's
+//     kernels end at about the same time as the next call's, so the download still starts late).
+//   * On a copy stream of its own behind an event (this code): 91-93 ms.  The runtime executes these copies as shader blits
+//     (a download that does not follow kernels of its own stream), which wait for compute units behind the persistent LSTM
+//     grids; a marker kernel in front of them does not change that.
+// A separate UPLOAD stream as well made everything serial (141 ms): streams beyond the runtime's hardware queues share one.
 int umx_hip_ctx::queue_download(const DeferredDownload &d, hipStream_t on)
 {
     Slot &src = slot[d.si];
     if (on != src.stream)
-    {
         UMX_HIP_CHECK(hipStreamWaitEvent(on, src.k_done, 0));
-        // a download that does not follow a kernel on its stream is run as shader blits by this runtime (observed, round 3):
-        // 128 copy KERNELS per step that cannot get a compute unit while a persistent LSTM grid holds all of them.  Behind a
-        // kernel -- any kernel -- the DMA engines are used, which run beside everything at the link's 55 GB/s.
-        hipLaunchKernelGGL(copy_stream_marker_kernel, dim3(1), dim3(64), 0, on);
-    }
     for (int ln = 0; ln < d.nb; ++ln)
         if (d.n[ln] > 0)
             for (int s2 = 0; s2 < 4; ++s2)
@@ -1300,18 +1295,8 @@ int umx_hip_ctx::queue_download(const DeferredDownload &d, hipStream_t on)
     return UMX_OK;
 }
 
-int umx_hip_ctx::flush_deferred()
-{
-    if (!deferred.valid)
-        return UMX_OK;
-    deferred.valid = false;
-    return queue_download(deferred, slot[deferred.si].stream);
-}
-
 int umx_hip_ctx::sync_all()
 {
-    if (int rc = flush_deferred())
-        return rc;
     for (int si = 0; si < nslots; ++si)
         UMX_HIP_CHECK(hipStreamSynchronize(slot[si].stream));
     if (copy_stream)
@@ -2443,6 +2428,10 @@ int umx_hip_ctx::recover()
     for (int l = 0; l < 3; ++l) // layer l of every (lane, target): 4 * Hl floats every 12 * Hl
         UMX_HIP_CHECK(hipMemcpy2D(state + (size_t)l * 4 * Hl, sizeof(float) * 12 * Hl, backup + (size_t)l * per * B + (size_t)l * 4 * Hl,
                                   sizeof(float) * 12 * Hl, sizeof(float) * 4 * Hl, (size_t)B * 4, hipMemcpyDeviceToDevice));
+    // hipMemset / device-to-device hipMemcpy on the null stream return before the device has done them, and the slots'
+    // streams are non-blocking (they do not order against the null stream): without this wait the replayed kernels could
+    // read the state before it is restored
+    UMX_HIP_CHECK(hipStreamSynchronize(nullptr));
     clear_used();
     recovering = true;
     int rc = UMX_OK;
@@ -2584,6 +2573,10 @@ int umx_hip_track_stream_reset(umx_hip_ctx *ctx, int track)
     const size_t per = ctx->state_floats();
     hipError_t e = track < 0 ? hipMemset(ctx->state, 0, sizeof(float) * per * ctx->B)
                              : hipMemset(ctx->state + per * track, 0, sizeof(float) * per);
+    // hipMemset returns before the device has done it, and the slots' non-blocking streams do not order against the null
+    // stream: the next segment's kernels must not meet the old state (found in round 3: a rare first-run mismatch)
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess)
     {
         ctx->set_error(hipGetErrorString(e));
@@ -2872,6 +2865,7 @@ int umx_hip_sync(umx_hip_ctx *ctx)
                                          : "persistent LSTM kernel timed out waiting for a hidden-state granule (code " + std::to_string(st) + ")";
             for (int sj = 0; sj < ctx->nslots; ++sj)
                 (void)hipMemset(ctx->slot[sj].status, 0, sizeof(unsigned));
+            (void)hipStreamSynchronize(nullptr); // (null-stream memsets are not ordered against the slots' non-blocking streams)
             ctx->persistent_ok = false; // later launches use the per-step driver
             const size_t ncalls = ctx->pending.size();
             if (!ctx->no_recovery && !ctx->pending_lost && ncalls >= 1 && ncalls <= (size_t)umx_hip_ctx::kBackupCalls)
@@ -2886,6 +2880,7 @@ int umx_hip_sync(umx_hip_ctx *ctx)
             }
             // no way back: the aborted launch left a mix of updated and stale chains behind
             (void)hipMemset(ctx->state, 0, sizeof(float) * ctx->state_floats() * ctx->B);
+            (void)hipStreamSynchronize(nullptr);
             ctx->clear_used();
             ctx->pending.clear();
             ctx->pending_lost = false;
@@ -2933,19 +2928,9 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
         }
         ain[ln] = dst;
     }
-    if (ctx->deferred.valid && ctx->deferred.si == si) // (only after a phased segment broke the alternation)
-        if (int rc = ctx->flush_deferred())
-            return rc;
     if (int rc = ctx->infer_batch(n_tracks, ain, n, ctx->stage_out[si], flags))
         return rc;
     UMX_HIP_CHECK_CTX(ctx, hipEventRecord(sl.k_done, st));
-    static const bool on_copy_stream = !(getenv("UMX_D2H") && std::string(getenv("UMX_D2H")) == "other");
-    if (ctx->deferred.valid && !on_copy_stream) // the previous call's stems: out behind this call's kernels, beside the next call's
-    {
-        ctx->deferred.valid = false;
-        if (int rc = ctx->queue_download(ctx->deferred, st))
-            return rc;
-    }
     if (!ctx->pending_lost && !ctx->pending.empty())
     {
         for (int k = 0; k < 4 * n_tracks; ++k)
@@ -2953,18 +2938,18 @@ int umx_hip_infer_batch_async(umx_hip_ctx *ctx, int n_tracks, const float *const
         for (int ln = 0; ln < n_tracks; ++ln)
             ctx->pending.back().host_audio[ln] = ain[ln] ? audio_host[ln] : nullptr;
     }
-    ctx->deferred.valid = !on_copy_stream;
-    ctx->deferred.si = si;
-    ctx->deferred.nb = n_tracks;
+    // the stems go out on the copy stream as soon as they are complete, beside whatever runs next (see queue_download)
+    umx_hip_ctx::DeferredDownload d;
+    d.valid = true;
+    d.si = si;
+    d.nb = n_tracks;
     for (int ln = 0; ln < n_tracks; ++ln)
     {
-        ctx->deferred.n[ln] = ain[ln] ? n[ln] : 0;
+        d.n[ln] = ain[ln] ? n[ln] : 0;
         for (int s = 0; s < 4; ++s)
-            ctx->deferred.host[4 * ln + s] = out_host[4 * ln + s];
+            d.host[4 * ln + s] = out_host[4 * ln + s];
     }
-    if (on_copy_stream) // the stems go out on the copy stream as soon as they are complete, beside whatever runs next
-        return ctx->queue_download(ctx->deferred, ctx->copy_stream);
-    return UMX_OK;
+    return ctx->queue_download(d, ctx->copy_stream);
 }
 
 int umx_hip_infer_batch(umx_hip_ctx *ctx, int n_tracks, const float *const *audio_host, const int *n, float *const *out_host,
