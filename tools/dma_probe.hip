@@ -51,6 +51,42 @@ template <int FULL> __global__ __launch_bounds__(1024) void probe(const unsigned
         *sink = acc;
 }
 
+// ---- the alternative to LDS-DMA: the same 16 rows x 64 B per wave-instruction as plain buffer_load_dwordx4 into registers,
+// then ds_write_b128 -- DEPTH loads in flight per wave.  If the DMA path moves one 16-byte lane per clock and CU (7.5 TB/s is
+// 14 B per clock and CU), this form is bound by the vector memory path (64 B per clock and CU) instead.
+template <int DEPTH> __global__ __launch_bounds__(1024) void probe_reg(const unsigned short *src, int row_bytes, int reps, unsigned *sink)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(src), 0, 0x7fffffff, 0x00020000);
+    const long band = (long)blockIdx.x * 256 * row_bytes;
+    const int voff = (lane >> 2) * row_bytes + (lane & 3) * 16;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    unsigned acc = 0;
+    const int nk = row_bytes / 64; // 64-byte K slices; a wave fetches its 16 rows of every slice
+    for (int r = 0; r < reps; ++r)
+    {
+        v4u q[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            q[d] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(band + (long)wave * 16 * row_bytes + d * 64), 0);
+        for (int k = 0; k < nk; k += DEPTH)
+        {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+            {
+                const v4u cur = q[d];
+                if (k + DEPTH + d < nk)
+                    q[d] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (int)(band + (long)wave * 16 * row_bytes + (k + DEPTH + d) * 64), 0);
+                *reinterpret_cast<v4u *>(smem + (((k + d) & 1) * 16384) + wave * 1024 + lane * 16) = cur;
+            }
+            acc += smem[(lane * 16 + k) & 32767];
+        }
+    }
+    if (acc == 0x12345678u)
+        *sink = acc;
+}
+
 // ---- the same sweep with the source coming from HBM (4 GiB, read once): rows as they lie in a row-major plane (every
 // wave-instruction takes 64 bytes out of 16 different rows, 5952 or 2048 bytes apart) against a K-tiled plane, where the 256
 // rows x 64 bytes of one (row band, K step) are one contiguous 16 KiB block (a wave-instruction = 1 KiB contiguous)
@@ -140,6 +176,26 @@ int main()
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
             printf("%s lines: %.3f ms, %.2f TB/s into LDS\n", full ? "full (8 rows x 128 B)" : "half (16 rows x 64 B)", ms,
+                   (double)rows * row_bytes * reps / (ms * 1e-3) / 1e12);
+        }
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe_reg<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe_reg<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe_reg<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    for (int depth : {2, 4, 8})
+        for (int it = 0; it < 3; ++it)
+        {
+            hipEventRecord(e0);
+            if (depth == 2)
+                hipLaunchKernelGGL(probe_reg<2>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, reps, sink);
+            else if (depth == 4)
+                hipLaunchKernelGGL(probe_reg<4>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, reps, sink);
+            else
+                hipLaunchKernelGGL(probe_reg<8>, dim3(256), dim3(1024), 65536, 0, src, row_bytes, reps, sink);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("registers + ds_write_b128, %d loads in flight per wave: %.3f ms, %.2f TB/s into LDS\n", depth, ms,
                    (double)rows * row_bytes * reps / (ms * 1e-3) / 1e12);
         }
     hbm_runs(sink);

@@ -333,14 +333,23 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
     else
         GP_WAIT(0);
     __syncthreads();
+// timing experiments (results are garbage): which side of the main loop sets its pace?
+#ifndef GP_EXPERIMENT_NO_DMA
+#define GP_EXPERIMENT_NO_DMA 0
+#endif
+#ifndef GP_EXPERIMENT_NO_MFMA
+#define GP_EXPERIMENT_NO_MFMA 0
+#endif
     if (STAGES == 3)
     {
         int cur = 0; // stage of tile kt; kt + 2 goes where kt - 1 was (last read before the previous barrier)
         for (int kt = 0; kt < nk - 2; ++kt)
         {
             const int nxt = cur == 0 ? 2 : cur - 1; // (cur + 2) % 3
-            GP_DMA(nxt, (kt + 2) * GP_BK)
-            GP_COMPUTE(cur)
+            if (!GP_EXPERIMENT_NO_DMA)
+                GP_DMA(nxt, (kt + 2) * GP_BK)
+            if (!GP_EXPERIMENT_NO_MFMA)
+                GP_COMPUTE(cur)
             GP_WAIT(DMA_PER_WAVE); // tile kt + 1 has landed, kt + 2 may be in flight
             __syncthreads();
             cur = cur == 2 ? 0 : cur + 1;
@@ -359,8 +368,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
         for (int kt = 0; kt < nk - 1; ++kt)
         {
             const int cur = kt & 1;
-            GP_DMA(cur ^ 1, (kt + 1) * GP_BK) // the other buffer was last read before the previous barrier
-            GP_COMPUTE(cur)
+            if (!GP_EXPERIMENT_NO_DMA)
+                GP_DMA(cur ^ 1, (kt + 1) * GP_BK) // the other buffer was last read before the previous barrier
+            if (!GP_EXPERIMENT_NO_MFMA)
+                GP_COMPUTE(cur)
             GP_WAIT(0);
             __syncthreads();
         }
