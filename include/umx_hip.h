@@ -202,8 +202,12 @@ void *umx_hip_stream_handle(umx_hip_ctx *ctx); /* the internal hipStream_t the m
  * in HBM, one download of the 4 stems.  Resets the streaming state first (umx.cpp:167-171).  Bit-identical to
  * umx_split_inference / umx_shift_inference of umx_host.h driving umx_hip_infer_segment; sum_weight is zeroed
  * (SURVEY F4).  offset: samples of leading silence inside the MAX_SHIFT buffer (umx.cpp:115); < 0 = the
- * reference's unseeded rand() % 22050.  progress (may be NULL) is called once per QUEUED segment. */
+ * reference's unseeded rand() % 22050 = UMX_REFERENCE_SHIFT.  progress (may be NULL) is called once per QUEUED segment. */
 #define UMX_MAX_SHIFT 22050 /* inference.hpp:14 MAX_SHIFT_SECS * 44100 */
+/* umx.cpp:115 draws rand() % 22050 and the reference never seeds rand(): with glibc every run of its CLI shifts by these
+ * 4033 samples.  "offset < 0" below means THIS value, not a call of rand() here -- in a process that links the HIP runtime
+ * (or anything else that draws from rand() first) the first rand() is no longer the reference's (found by a test, round 3). */
+#define UMX_REFERENCE_SHIFT 4033
 int umx_hip_split_inference(umx_hip_ctx *ctx, const float *audio_host, int length, float *const out_host[4],
                             unsigned flags, void (*progress)(float, void *), void *progress_user);
 int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int length, int offset, float *const out_host[4],

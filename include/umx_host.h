@@ -71,7 +71,7 @@ typedef struct umx_backend
 int umx_split_inference(const umx_backend *be, const float *audio, int length, int segment_samples,
                         float *const out[4], void (*progress)(float, void *), void *progress_user, char *err);
 /* umx.cpp:99-150: delay by `offset` inside a zero buffer of length+22050-offset samples, split, trim.
- * offset < 0 -> rand() % 22050 like the reference (unseeded glibc rand(): 4033). */
+ * offset < 0 -> the reference's rand() % 22050 (unseeded glibc rand(): UMX_REFERENCE_SHIFT = 4033). */
 int umx_shift_inference(const umx_backend *be, const float *audio, int length, int segment_samples,
                         int offset, float *const out[4], void (*progress)(float, void *), void *progress_user,
                         char *err);

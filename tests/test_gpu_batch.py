@@ -318,3 +318,20 @@ def test_whole_tracks_as_track_lanes_and_the_batch_cli(pkg, po, tmp_path):
             assert ch == 2 and np.abs(g - ref[t]).max() < TOL_WAVE, (name, t)
     bad = subprocess.run([str(cli), path], capture_output=True, text=True)
     assert bad.returncode == 1 and "Usage" in bad.stderr
+    # two inputs with the same file name must not overwrite each other, and every file -- in whatever batch
+    # of lanes it lands -- gets the reference's one unseeded rand() % 22050 = 4033 (umx.cpp:115) unless UMX_SHIFT_OFFSET says otherwise
+    import shutil
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    shutil.copy(gold / "gspi_stereo.wav", tmp_path / "a" / "x.wav")
+    shutil.copy(gold / "gspi_mono.wav", tmp_path / "b" / "x.wav")
+    out2 = tmp_path / "out2"
+    env2 = {k: v for k, v in __import__("os").environ.items() if k != "UMX_SHIFT_OFFSET"}
+    r = subprocess.run([str(cli), path, str(out2), str(tmp_path / "a" / "x.wav"), str(tmp_path / "b" / "x.wav")], capture_output=True, text=True,
+                       env=env2, timeout=600)
+    assert r.returncode == 0, r.stderr
+    for name, src in (("x", "gspi_stereo"), ("x_2", "gspi_mono")):
+        for t in range(4):
+            g, _ = pkg.wav_load(out2 / name / f"target_{t}.wav")
+            ref, _ = pkg.wav_load(out / src / f"target_{t}.wav")  # written above with UMX_SHIFT_OFFSET=4033
+            assert (g == ref).all(), (name, t)

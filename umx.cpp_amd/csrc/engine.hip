@@ -2669,7 +2669,7 @@ int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int lengt
     if (!ctx)
         return UMX_ERR_ARG;
     if (offset < 0)
-        offset = rand() % UMX_MAX_SHIFT; // umx.cpp:115 (never seeded in the reference)
+        offset = UMX_REFERENCE_SHIFT; // umx.cpp:115: rand() % 22050, never seeded in the reference (see umx_hip.h)
     return ctx->track(audio_host, length, offset, out_host, flags, progress, progress_user);
 }
 

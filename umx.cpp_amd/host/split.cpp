@@ -126,7 +126,7 @@ extern "C" int umx_shift_inference(const umx_backend *be, const float *audio, in
     }
     const int max_shift = UMX_MAX_SHIFT_SAMPLES; // umx.cpp:112-113
     if (offset < 0)
-        offset = rand() % max_shift; // umx.cpp:115 (never seeded in the reference)
+        offset = UMX_REFERENCE_SHIFT; // umx.cpp:115: rand() % 22050, never seeded in the reference (see umx_hip.h)
     if (offset >= max_shift)
     {
         seterr(err, "shift offset must be < 22050");

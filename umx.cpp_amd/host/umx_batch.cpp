@@ -54,7 +54,7 @@ int main(int argc, const char **argv)
     umx_model_free(model);
     const unsigned flags = env_int("UMX_NO_WIENER", 0) ? UMX_FLAG_NO_WIENER : 0;
     double audio_secs = 0, wall = 0;
-    const int first_rand_shift = rand() % UMX_MAX_SHIFT; // glibc, unseeded: 4033
+    const int first_rand_shift = UMX_REFERENCE_SHIFT; // glibc's first unseeded rand() % 22050 (not rand() here: umx_hip.h)
     std::set<std::string> used_names; // output directories are named after the file's stem: a/x.wav and b/x.wav must not collide
     for (int f0 = 0; f0 < nfiles; f0 += lanes)
     {
