@@ -340,20 +340,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
 #ifndef GP_EXPERIMENT_NO_MFMA
 #define GP_EXPERIMENT_NO_MFMA 0
 #endif
+#ifndef GP_PROFILE
+#define GP_PROFILE 0 // 1: one wave of one workgroup per launch prints where the cycles of its main loop go (timing build)
+#endif
+    [[maybe_unused]] long long pf[4] = {0, 0, 0, 0};
     if (STAGES == 3)
     {
         int cur = 0; // stage of tile kt; kt + 2 goes where kt - 1 was (last read before the previous barrier)
         for (int kt = 0; kt < nk - 2; ++kt)
         {
             const int nxt = cur == 0 ? 2 : cur - 1; // (cur + 2) % 3
+            [[maybe_unused]] long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (GP_PROFILE)
+                c0 = clock64();
             if (!GP_EXPERIMENT_NO_DMA)
                 GP_DMA(nxt, (kt + 2) * GP_BK)
+            if (GP_PROFILE)
+                c1 = clock64();
             if (!GP_EXPERIMENT_NO_MFMA)
                 GP_COMPUTE(cur)
+            if (GP_PROFILE)
+                c2 = clock64();
             GP_WAIT(DMA_PER_WAVE); // tile kt + 1 has landed, kt + 2 may be in flight
+            if (GP_PROFILE)
+                c3 = clock64();
             __syncthreads();
+            if (GP_PROFILE)
+            {
+                const long long c4 = clock64();
+                pf[0] += c1 - c0;
+                pf[1] += c2 - c1;
+                pf[2] += c3 - c2;
+                pf[3] += c4 - c3;
+            }
             cur = cur == 2 ? 0 : cur + 1;
         }
+        if (GP_PROFILE && blockIdx.x == 64 && blockIdx.z == 0 && (tid == 0 || tid == 64 * 7))
+            printf("# gemm_planes<%d,%d> wave %d trips %d: cycles per trip  dma-issue %lld  fragments+mfma %lld  wait-dma %lld  barrier %lld\n", MODE, NBP,
+                   wave, nk - 2, pf[0] / (nk - 2), pf[1] / (nk - 2), pf[2] / (nk - 2), pf[3] / (nk - 2));
         if (nk > 1)
         {
             GP_COMPUTE(cur)
