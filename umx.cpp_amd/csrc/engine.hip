@@ -1240,7 +1240,9 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 2))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
         UMX_GP_ATTR(G_FC1)
         UMX_GP_ATTR(G_IH)
         UMX_GP_ATTR(G_FC2)
@@ -1682,8 +1684,15 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     const int bm = big ? 256 : 128;
     const dim3 grid((unsigned)round_up((g.N / bm) * (g.M / bm), 8), 1, nact), block(big ? 1024 : 256);
     const size_t lds = big ? gp_lds_bytes(4, 4, nbp) : gp_lds_bytes(2, 2, nbp);
+    // 256 x 256 blocks: 16 waves of 64 x 64 or 8 waves of 128 x 64 (gemm_planes.h: same bits).  Measured alone, 32 lanes,
+    // two A/B pairs on one box (round 3): fc1 5.92-5.97 -> 5.73-5.76 ms, W_ih 5.76 -> 5.66-5.70, fc2 4.59-4.63 -> 4.42-4.58,
+    // fc3 8.88-8.99 -> 9.02-9.12: eight waves for the one-plane (u8) weights, sixteen for the two-plane ones.
+    static const int gemm_waves = getenv("UMX_GEMM_WAVES") ? atoi(getenv("UMX_GEMM_WAVES")) : 0; // 0: by weight planes
+    const bool w8 = big && (gemm_waves == 8 || (gemm_waves == 0 && nbp == 1));
 #define UMX_GP(MODE)                                                                                                 \
-    if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);           \
+    if (w8 && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 2, 4, 4>), grid, dim3(512), lds, st, g);      \
+    else if (w8) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 4, 4>), grid, dim3(512), lds, st, g);            \
+    else if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);           \
     else if (big) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 4, 4>), grid, block, lds, st, g);                  \
     else if (nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 2, 2>), grid, block, lds, st, g);             \
     else hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 2>), grid, block, lds, st, g);

@@ -219,13 +219,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs a)
     }
 }
 
-template <int MODE, int NBP, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_planes_kernel(GemmPArgs args)
+// MI = 32-row matrix tiles per wave along M (2: wave tile 64 x 64, the 16-wave form of the 256 x 256 block; 4: wave tile
+// 128 x 64, EIGHT waves of up to 256 registers for the same block -- 10 instead of 12 fragment reads per 16 matrix
+// instructions, half as many parties at the barrier; round 3, profiles/r03_gemm_pace_experiments.txt).  Every accumulator
+// sees the same sequence of matrix instructions in either form: the results are bit-identical.  Worth 1-3 % on the u8
+// GEMMs, nothing on the u16 ones: the trip's pace is the matrix pipe's at the clock the chip holds under this load.
+template <int MODE, int NBP, int WM, int WN, int MI = 2>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN * MI >= 32) ? 1 : 2) void gemm_planes_kernel(GemmPArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];
-    constexpr int BM = 64 * WM, BN = 64 * WN, NW = WM * WN;
+    constexpr int BM = 32 * MI * WM, BN = 64 * WN, NW = WM * WN;
     constexpr int A_PL = BM * 64, B_PL = BN * 64; // bytes of one plane tile of each operand
-    constexpr int BUF_BYTES = 2 * A_PL + NBP * B_PL, STAGES = gp_stages(WM, WN, NBP);
+    constexpr int BUF_BYTES = 2 * A_PL + NBP * B_PL, STAGES = gp_stages(BM / 64, WN, NBP);
+    static_assert(MI == 2 || MI == 4, "wave tile 64 x 64 or 128 x 64");
     static_assert(NBP == 1 || NBP == 2, "weight planes: 1 (u8) or 2 (u16, fp32)");
     const GemmPTarget tg = args.t[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,28 +287,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
         }                                                                                                            \
     }
 
-    floatx16 acc00, acc01, acc10, acc11;
+    floatx16 acc[MI][2]; // [32-row tile along M][32-column tile along N] of the wave's (32 MI) x 64 block
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-    {
-        acc00[r] = 0.f;
-        acc01[r] = 0.f;
-        acc10[r] = 0.f;
-        acc11[r] = 0.f;
-    }
-    // fragment of rows (w*64 + mi*32 + lr), k = kk*16 + lh*8 .. +8: logical chunk 2 kk + lh, swizzled by the row
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+            acc[mi][0][r] = 0.f;
+            acc[mi][1][r] = 0.f;
+        }
+    // fragment of rows (w*32*MI + mi*32 + lr), k = kk*16 + lh*8 .. +8: logical chunk 2 kk + lh, swizzled by the row
     const int sw = (lr >> 2) & 3; // rows 32 apart share it
-    const int fragA = (wm * 64 + lr) * 64, fragB = 2 * A_PL + (wn * 64 + lr) * 64;
+    const int fragA = (wm * 32 * MI + lr) * 64, fragB = 2 * A_PL + (wn * 64 + lr) * 64;
 #define GP_LD(off) (*reinterpret_cast<const f16x8 *>(gp_smem + (off)))
 #define GP_MFMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0);
 #define GP_TERM(PA, PB, KK)                                                                                          \
     {                                                                                                                \
         const int co = (((KK)*2 + lh) ^ sw) * 16;                                                                    \
-        const f16x8 a0 = GP_LD(bo + fragA + (PA)*A_PL + co);                                                         \
-        const f16x8 a1 = GP_LD(bo + fragA + (PA)*A_PL + 32 * 64 + co);                                               \
         const f16x8 b0 = GP_LD(bo + fragB + (PB)*B_PL + co);                                                         \
         const f16x8 b1 = GP_LD(bo + fragB + (PB)*B_PL + 32 * 64 + co);                                               \
-        GP_MFMA(a0, b0, acc00) GP_MFMA(a0, b1, acc01) GP_MFMA(a1, b0, acc10) GP_MFMA(a1, b1, acc11)                  \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                            \
+        {                                                                                                            \
+            const f16x8 am = GP_LD(bo + fragA + (PA)*A_PL + mi * 32 * 64 + co);                                      \
+            GP_MFMA(am, b0, acc[mi][0]) GP_MFMA(am, b1, acc[mi][1])                                                  \
+        }                                                                                                            \
     }
     // smallest terms first
 #define GP_COMPUTE(buf)                                                                                              \
@@ -423,27 +431,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
         }
         __syncthreads();
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
             {
-                const int ml = wm * 64 + mi * 32 + 8 * rq + 4 * lh; // rows (r & 3) + 8 (r >> 2) + 4 lh, r = 4 rq + j
+                const int ml = wm * 32 * MI + mi * 32 + 8 * rq + 4 * lh; // rows (r & 3) + 8 (r >> 2) + 4 lh, r = 4 rq + j
                 const float4 mu = *reinterpret_cast<const float4 *>(fx + ml), ad = *reinterpret_cast<const float4 *>(fx + BM + ml);
                 const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, ads[4] = {ad.x, ad.y, ad.z, ad.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                 {
                     const int r = 4 * rq + j;
-                    if (mi == 0)
-                    {
-                        acc00[r] = mus[j] * acc00[r] + ads[j];
-                        acc01[r] = mus[j] * acc01[r] + ads[j];
-                    }
-                    else
-                    {
-                        acc10[r] = mus[j] * acc10[r] + ads[j];
-                        acc11[r] = mus[j] * acc11[r] + ads[j];
-                    }
+                    acc[mi][0][r] = mus[j] * acc[mi][0][r] + ads[j];
+                    acc[mi][1][r] = mus[j] * acc[mi][1][r] + ads[j];
                 }
                 asm volatile("" ::: "memory"); // keep the next group's reads behind this group's arithmetic
             }
@@ -459,7 +459,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
     ea.Tp_lane = args.Tp_lane;
     ea.lanes = args.lanes;
     ea.mag_lane = args.mag_lane;
-    gemm_epilogue<MODE>(et, ea, m0, n0, wm, wn, lr, lh, acc00, acc01, acc10, acc11);
+    // the shared epilogue takes a 64 x 64 wave tile at rows m0 + 64 wm: a 128 x 64 wave tile is two of them
+#pragma unroll
+    for (int half = 0; half < MI / 2; ++half)
+        gemm_epilogue<MODE>(et, ea, m0 + wm * 32 * MI + half * 64, n0, 0, wn, lr, lh, acc[2 * half][0], acc[2 * half][1], acc[2 * half + 1][0],
+                            acc[2 * half + 1][1]);
 }
 
 } // namespace umx
