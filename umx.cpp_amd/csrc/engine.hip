@@ -1620,7 +1620,13 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
         }
     }
     a.rows_valid = nl * Tp;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(round_up(nl * Tp, 256), 1, nact), dim3(256), 0, st, a);
+    const dim3 grid(round_up(nl * Tp, 256) / 4, 1, nact);
+    if (a.cols <= 1024)
+        hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, st, a);
+    else if (a.cols <= 3072)
+        hipLaunchKernelGGL(split_planes_kernel<6>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(split_planes_kernel<8>, grid, dim3(256), 0, st, a);
 }
 
 void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg)

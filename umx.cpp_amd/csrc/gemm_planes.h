@@ -110,7 +110,7 @@ __host__ inline float f16_bits_to_float(unsigned short h)
 }
 
 // split_planes_kernel: fp32 rows -> two fp16 planes of the scaled row + row sum + inverse scale.
-// grid (rows_out, 1, targets), 256 threads, at most 16 elements per thread (cols <= 4096).
+// grid (rows_out / 4, 1, targets), 256 threads = four rows; cols <= 512 ITER.
 struct SplitArgs
 {
     const float *src[4];
@@ -139,24 +139,29 @@ __device__ __forceinline__ void split2_f16(const float (&x)[8], float scale, uin
     p2 = *reinterpret_cast<uint4 *>(&h2);
 }
 
-__global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs a)
+// One WAVE per row (four rows per 256-thread workgroup), ITER x 512 columns: lane l holds the 8 consecutive elements
+// k = (it * 64 + l) * 8 of its row, so a wave reads 2 KiB and writes 2 x 1 KiB contiguous per iteration; row sum and
+// row maximum by lane exchanges only (round 2's form used one 256-thread workgroup per row -- half of them idle for the
+// 1024-column operands -- two barriers and an LDS round trip: 0.72 ms per 32-lane launch at 3.7 TB/s).
+template <int ITER> __global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs a)
 {
-    __shared__ float red[4], redm[4];
-    const int m = blockIdx.x, tg = blockIdx.z, tid = threadIdx.x;
+    const int tg = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int m = blockIdx.x * 4 + (tid >> 6); // the grid covers rows_out (a multiple of 256) rows
     const float *src = a.src[tg] + (size_t)m * a.ld_src;
     unsigned short *dst = a.dst[tg] + (size_t)m * a.ld_dst + a.col0_dst;
     const float *sc = a.scale[tg], *mn = a.mean[tg];
     const bool adaptive = a.rowunscale[tg] != nullptr;
-    float xs[2][8];
+    const bool live = m < a.rows_valid && m % a.Tp < a.T; // rows of the M padding are zero planes
+    float xs[ITER][8];
     float sum = 0.f, mx = 0.f;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < ITER; ++it)
     {
-        const int k = tid * 8 + it * 2048;
+        const int k = (it * 64 + lane) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             xs[it][j] = 0.f;
-        if (k < a.cols && m < a.rows_valid && m % a.Tp < a.T) // rows of the M padding are zero planes
+        if (k < a.cols && live)
         {
             const float4 v0 = *reinterpret_cast<const float4 *>(src + k), v1 = *reinterpret_cast<const float4 *>(src + k + 4);
             xs[it][0] = v0.x; xs[it][1] = v0.y; xs[it][2] = v0.z; xs[it][3] = v0.w;
@@ -171,44 +176,37 @@ __global__ __launch_bounds__(256) void split_planes_kernel(SplitArgs a)
         for (int j = 0; j < 8; ++j)
             mx = fmaxf(mx, fabsf(xs[it][j]));
     }
-    // row sum in a fixed order (lanes by xor-shuffle, then the four waves); row maximum alongside
+    // row sum in a fixed order (per lane in column order, then the lanes by xor-exchange); row maximum alongside
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
     {
         sum += __shfl_xor(sum, off, 64);
         mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     }
-    if ((tid & 63) == 0)
-    {
-        red[tid >> 6] = sum;
-        redm[tid >> 6] = mx;
-    }
-    __syncthreads();
     float scale = (float)(1 << GP_SPLIT_FIXED_EXP), unscale = 1.0f / (float)(1 << GP_SPLIT_FIXED_EXP);
     if (adaptive)
     {
-        const float rmax = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
         int e = 0;
-        if (rmax > 0.f && rmax < 3.0e38f)
+        if (mx > 0.f && mx < 3.0e38f)
         {
             int x;
-            (void)frexpf(rmax, &x); // rmax = f 2^x, f in [0.5, 1)
+            (void)frexpf(mx, &x); // mx = f 2^x, f in [0.5, 1)
             e = min(max(GP_SPLIT_FIXED_EXP + 1 - x, -100), 100);
         }
         scale = ldexpf(1.0f, e);
         unscale = ldexpf(1.0f, -e);
     }
-    if (tid == 0)
+    if (lane == 0)
     {
         if (a.rowsum[tg])
-            a.rowsum[tg][m] = (red[0] + red[1]) + (red[2] + red[3]);
+            a.rowsum[tg][m] = sum;
         if (adaptive)
             a.rowunscale[tg][m] = unscale;
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < ITER; ++it)
     {
-        const int k = tid * 8 + it * 2048;
+        const int k = (it * 64 + lane) * 8;
         if (k < a.cols)
         {
             uint4 p1, p2;
