@@ -87,3 +87,23 @@ def test_rccl_path_ranks_on_one_device(pkg, model_small, tmp_path, world):
     eng.close()
     assert got.shape == one.shape
     assert (got == one).all()
+
+
+@pytest.mark.parametrize("mode", ["track", "targets"])
+def test_bench_track_modes_run_through_rccl_in_loopback(mode):
+    """`bench.py --mode track | targets` (BASELINE config 4) is the driver's entry for N > 1; on the one-GPU box it runs through
+    the same C++ driver with every transfer an RCCL self send + receive (--loopback): one JSON line with the contract's
+    fields, the RCCL operation counts of the track, finite outputs."""
+    import json
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--mode", mode, "--loopback", "--track-seconds", "130", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["outputs_finite"] and d["scaling"] == "strong"
+    nseg = d["config"]["segments"]
+    rc = d["config"]["rccl"]
+    assert rc["state_hops"] == 2 * 4 * 3 * (nseg - 1) and rc["stem_transfers"] == 4 * nseg and rc["retries"] == 0
