@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B runner for kernel variants on the GPU box: tools/ab.py <outdir> <tracks,tracks,..> <variant .so or 'default'> ...
+"""A/B runner for kernel variants on the GPU box: tools/ab.py <outdir> <tracks,tracks,..> <variant .so | 'default' | env:NAME=VALUE[,NAME=VALUE]> ...
 Prints one compact line per (variant, tracks): ms/step, x realtime, stand-alone stage times, LSTM phase cycles."""
 import json
 import os
@@ -12,9 +12,11 @@ os.makedirs(out, exist_ok=True)
 for v in variants:
     for b in tracks:
         env = dict(os.environ)
-        if v != "default":
+        if v.startswith("env:"):
+            env.update(kv.split("=", 1) for kv in v[4:].split(","))
+        elif v != "default":
             env["UMX_HIP_LIB"] = os.path.abspath(v)
-        tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "")
+        tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "").replace("env:", "").replace("=", "")
         cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-single-track"] + extra
         if os.environ.get("AB_PROFILE"):  # the in-kernel profiler slows the profiled workgroup, and with it its whole chain
             cmd.append("--lstm-profile")
@@ -33,6 +35,8 @@ for v in variants:
         gemm = al["fc1"] + al["fc2"] + al["fc3_mask"] + sum(al[f"lstm_ih{l}"] for l in range(3))
         prof = [ln for ln in p.stderr.splitlines() if ln.startswith("# lstm alone layer 1 wave")]
         print(f"{tag:12s} B={b:2d} {j['ms_per_step']:8.3f} ms/step {j['value']:9.1f}x  alone: lstm/launch {lstm:7.3f} ms "
-              f"({lstm * 1e3 / j['config']['frames']:.3f} us/step) gemm {gemm:7.3f} serial {j['ms_per_step_unpipelined']:8.3f}", flush=True)
+              f"({lstm * 1e3 / j['config']['frames']:.3f} us/step) gemm {gemm:7.3f} serial {j['ms_per_step_unpipelined']:8.3f}  "
+              f"fc1 {al['fc1']:.2f} ih {al['lstm_ih0']:.2f}/{al['lstm_ih1']:.2f}/{al['lstm_ih2']:.2f} fc2 {al['fc2']:.2f} fc3 {al['fc3_mask']:.2f} "
+              f"chk {j.get('checked_max_abs')}", flush=True)
         for ln in prof:
             print("      ", ln[2:], flush=True)

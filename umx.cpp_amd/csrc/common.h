@@ -28,6 +28,17 @@ constexpr int LSTM_PERSISTENT_THREADS = 576; // + 1 gate wave in the persistent 
 
 __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// The streaming kernels (STFT, Wiener statistics / filter + inverse STFT, overlap-add) cover EVERY active track lane of a
+// call in one launch: a grid dimension runs over the entries of a LaneSet, and a lane's buffers sit a fixed stride apart
+// behind lane 0's (engine.hip allocates them that way).  One launch per kernel and call instead of one per lane: no
+// launch gaps and no partly filled last round of workgroups between the lanes (32 lanes: 192 -> 6 launches per call).
+constexpr int MAX_TRACK_LANES = 48; // = LSTMB_MAX_TRACKS (lstm_batch.h)
+struct LaneSet
+{
+    int count;
+    unsigned char id[MAX_TRACK_LANES]; // track lane of entry i
+};
+
 // a / b for a divisor that is reused: q = a * (1/b) corrected once with the exact remainder (Markstein): the
 // correctly rounded quotient, i.e. bit-identical to the IEEE division the reference's expression performs
 // (inference.cpp:94-95), in 3 instructions instead of the ~11 of v_div_scale / v_div_fmas / v_div_fixup.

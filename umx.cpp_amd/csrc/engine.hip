@@ -24,6 +24,7 @@
 #include "common.h"
 #include "gemm_bf16x3.h"
 #include "gemm_planes.h"
+#include "gemm_planes_pp.h"
 #include "lstm_kernels.h"
 #include "lstm_batch.h"
 #include "lstm_batch2.h"
@@ -431,6 +432,29 @@ struct umx_hip_ctx
     int sync_all();
     void launch_gemm(Lane &ln, hipStream_t st, int mode, int layer, const int *active, int nact, bool dbg);
     int stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active, int nact);
+    // elements between the streaming buffers of consecutive track lanes of a slot (the kernels take lane 0's pointers)
+    WienerStrides lane_strides() const
+    {
+        WienerStrides ls;
+        const size_t nchunk = (size_t)(T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+        ls.spec = (size_t)2 * T * NBINS;
+        ls.mag = (size_t)2 * T * MAGP;
+        ls.part = std::max((size_t)4 * nbatch * NBINS * 9, nchunk * 4 * 5 * NBINS);
+        ls.rc = (size_t)4 * NBINS * 4;
+        ls.r8 = (size_t)4 * NBINS * 8;
+        ls.frames = (size_t)4 * T * NFFT;
+        ls.y = (size_t)4 * 2 * T * NBINS;
+        return ls;
+    }
+    static LaneSet lane_set(int nb, const float *const *audio_dev) // the active lanes of a call
+    {
+        LaneSet l;
+        l.count = 0;
+        for (int ln = 0; ln < nb; ++ln)
+            if (audio_dev[ln])
+                l.id[l.count++] = (unsigned char)ln;
+        return l;
+    }
     int stage_back(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, float *const *out, const int *n,
                    unsigned flags, const int *active, int nact);
     // its two halves: fc2 + fc3 -> the target magnitudes of the active targets | Wiener (or mixture phase), inverse STFT,
@@ -1122,25 +1146,39 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 }
             }
         }
-        for (int ln = 0; ln < B; ++ln)
         {
-            Lane &L = sl.lane[ln];
-            L.x = x_all + (size_t)ln * Tp * KX;
-            if (int rc = dalloc(&L.spec, (size_t)2 * T * NBINS))
+            // every lane's streaming buffers a fixed stride apart (lane_strides()): the streaming kernels take lane 0's
+            // pointers and cover all active lanes in one launch (common.h LaneSet)
+            const WienerStrides ls = lane_strides();
+            float2 *spec_all, *y_all, *frames_all;
+            float *wpart_all, *R_all, *Rc_all;
+            unsigned *maxabs_all;
+            if (int rc = dalloc(&spec_all, (size_t)B * ls.spec))
                 return rc;
-            if (int rc = dalloc(&L.y, (size_t)4 * 2 * T * NBINS))
+            if (int rc = dalloc(&y_all, (size_t)B * ls.y))
                 return rc;
-            if (int rc = dalloc(&L.frames, (size_t)4 * T * NFFT))
+            if (int rc = dalloc(&frames_all, (size_t)B * ls.frames))
                 return rc;
-            const size_t nchunk = (size_t)(T + WIENER_CHUNK - 1) / WIENER_CHUNK;
-            if (int rc = dalloc(&L.wpart, std::max((size_t)4 * nbatch * NBINS * 9, nchunk * 4 * 5 * NBINS)))
+            if (int rc = dalloc(&wpart_all, (size_t)B * ls.part))
                 return rc;
-            if (int rc = dalloc(&L.R, (size_t)4 * NBINS * 8))
+            if (int rc = dalloc(&R_all, (size_t)B * ls.r8))
                 return rc;
-            if (int rc = dalloc(&L.Rc, (size_t)4 * NBINS * 4))
+            if (int rc = dalloc(&Rc_all, (size_t)B * ls.rc))
                 return rc;
-            if (int rc = dalloc(&L.maxabs, 4))
+            if (int rc = dalloc(&maxabs_all, (size_t)B))
                 return rc;
+            for (int ln = 0; ln < B; ++ln)
+            {
+                Lane &L = sl.lane[ln];
+                L.x = x_all + (size_t)ln * Tp * KX;
+                L.spec = spec_all + (size_t)ln * ls.spec;
+                L.y = y_all + (size_t)ln * ls.y;
+                L.frames = frames_all + (size_t)ln * ls.frames;
+                L.wpart = wpart_all + (size_t)ln * ls.part;
+                L.R = R_all + (size_t)ln * ls.r8;
+                L.Rc = Rc_all + (size_t)ln * ls.rc;
+                L.maxabs = maxabs_all + ln;
+            }
         }
         if (int rc = dalloc(&sl.status, 4))
             return rc;
@@ -1241,8 +1279,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 2))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2))); \
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_pp_kernel<MODE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_pp_kernel<MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
         UMX_GP_ATTR(G_FC1)
         UMX_GP_ATTR(G_IH)
         UMX_GP_ATTR(G_FC2)
@@ -1690,15 +1728,16 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     const int bm = big ? 256 : 128;
     const dim3 grid((unsigned)round_up((g.N / bm) * (g.M / bm), 8), 1, nact), block(big ? 1024 : 256);
     const size_t lds = big ? gp_lds_bytes(4, 4, nbp) : gp_lds_bytes(2, 2, nbp);
-    // 256 x 256 blocks: 16 waves of 64 x 64 or 8 waves of 128 x 64 (gemm_planes.h: same bits).  Measured alone, 32 lanes,
-    // two A/B pairs on one box (round 3): fc1 5.92-5.97 -> 5.73-5.76 ms, W_ih 5.76 -> 5.66-5.70, fc2 4.59-4.63 -> 4.42-4.58,
-    // fc3 8.88-8.99 -> 9.02-9.12: eight waves for the one-plane (u8) weights, sixteen for the two-plane ones.
-    static const int gemm_waves = getenv("UMX_GEMM_WAVES") ? atoi(getenv("UMX_GEMM_WAVES")) : 0; // 0: by weight planes
-    const bool w8 = big && (gemm_waves == 8 || (gemm_waves == 0 && nbp == 1));
+    // 256 x 256 blocks: 16 waves of 64 x 64 in lock step (gemm_planes.h), or eight waves of 128 x 64 in ping-pong
+    // (gemm_planes_pp.h: same bits).  Measured alone, 32 lanes, ms per launch incl. the split kernel, A/B on one box (round 3):
+    // fc1 5.70-5.98 -> 5.49-5.52, W_ih 5.69-6.14 -> 5.46-5.65, fc2 4.67-4.80 -> 4.76-4.96, fc3 9.00-9.20 -> 9.33-9.53:
+    // ping-pong for the one-plane (u8) weights, lock step for the two-plane ones.  UMX_GEMM_PP: bit per GemmMode.
+    static const int gemm_pp = getenv("UMX_GEMM_PP") ? atoi(getenv("UMX_GEMM_PP")) : -1;
+    const bool pp = big && (gemm_pp < 0 ? nbp == 1 : ((gemm_pp >> mode) & 1));
 #define UMX_GP(MODE)                                                                                                 \
-    if (w8 && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 2, 4, 4>), grid, dim3(512), lds, st, g);      \
-    else if (w8) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 4, 4>), grid, dim3(512), lds, st, g);            \
-    else if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);           \
+    if (pp && nbp == 1) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 1>), grid, dim3(512), lds, st, g);           \
+    else if (pp) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 2>), grid, dim3(512), lds, st, g);                  \
+    else if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);      \
     else if (big) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 4, 4>), grid, block, lds, st, g);                  \
     else if (nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 2, 2>), grid, block, lds, st, g);             \
     else hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 2, 2>), grid, block, lds, st, g);
@@ -1746,13 +1785,19 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
                              int nact)
 {
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_STFT], st));
-    for (int ln = 0; ln < nb; ++ln)
-        if (audio_dev[ln])
+    {
+        StftIn in;
+        in.lanes = lane_set(nb, audio_dev);
+        for (int i = 0; i < in.lanes.count; ++i)
         {
-            Lane &L = sl.lane[ln];
-            UMX_HIP_CHECK(hipMemsetAsync(L.maxabs, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(stft_kernel, dim3(T), dim3(256), 0, st, audio_dev[ln], n[ln], N, T, window, tw1, tw2, L.spec, L.x, L.maxabs);
+            in.audio[i] = audio_dev[in.lanes.id[i]];
+            in.n[i] = n[in.lanes.id[i]];
         }
+        Lane &L0 = sl.lane[0];
+        UMX_HIP_CHECK(hipMemsetAsync(L0.maxabs, 0, sizeof(unsigned) * B, st)); // per-call scratch of every lane
+        hipLaunchKernelGGL(stft_kernel, dim3(T, in.lanes.count), dim3(256), 0, st, in, N, T, window, tw1, tw2, L0.spec, lane_strides().spec, L0.x,
+                           (size_t)Tp * KX, L0.maxabs);
+    }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC1, 0, active, nact, false);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
@@ -1792,76 +1837,87 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
                         UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * MAGP, st));
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_WIENER], st));
     const int bt = (NBINS + 255) / 256;
-    for (int ln = 0; ln < nb; ++ln)
+    const LaneSet lanes = lane_set(nb, audio_dev);
+    const WienerStrides ls = lane_strides();
+    Lane &L0 = sl.lane[0]; // the batched kernels take lane 0's pointers and step by ls
+    WienerMags wm0;
+    for (int s = 0; s < 4; ++s)
+        wm0.m[s] = L0.ta[s].mag;
+    const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+    if (flags & UMX_FLAG_NO_WIENER)
     {
-        if (!audio_dev[ln])
-            continue;
-        Lane &L = sl.lane[ln];
-        WienerMags wm;
-        for (int s = 0; s < 4; ++s)
-            wm.m[s] = L.ta[s].mag;
-        const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
-        if (flags & UMX_FLAG_NO_WIENER)
-        {
-            if (!wiener_fused)
+        if (!wiener_fused)
+            for (int i = 0; i < lanes.count; ++i)
             {
-                const size_t nel = (size_t)2 * T * NBINS;
-                hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, L.spec, wm, T, L.y);
-            }
-        }
-        else
-        {
-            {
-                static const int ns = getenv("UMX_WIENER_NS") ? atoi(getenv("UMX_WIENER_NS")) : 2; // sources per thread (measured: 4: 0.151, 2: 0.128, 1: 0.131 ms per track)
-                const dim3 g((NBINS + 63) / 64, nchunk, 4 / (ns == 1 || ns == 2 ? ns : 4));
-                if (ns == 1)
-                    hipLaunchKernelGGL(wiener_stats4_kernel<1>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
-                else if (ns == 2)
-                    hipLaunchKernelGGL(wiener_stats4_kernel<2>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
-                else
-                    hipLaunchKernelGGL(wiener_stats4_kernel<4>, g, dim3(64), 0, st, L.spec, wm, T, L.maxabs, L.wpart);
-                hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4), dim3(256), 0, st, L.wpart, T, L.Rc, wiener_fused ? nullptr : L.R);
-            }
-            if (!wiener_fused)
-                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
-        }
-    }
-    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
-    for (int ln = 0; ln < nb; ++ln)
-        if (audio_dev[ln])
-        {
-            Lane &L = sl.lane[ln];
-            if (!wiener_fused)
-                hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, L.y, T, window, nw, tw1, tw2, L.frames);
-            else
-            {
-                // gains + filter + inverse STFT frame in one pass (wiener_istft.h); y reaches HBM only for the debug tap
+                Lane &L = sl.lane[lanes.id[i]];
                 WienerMags wm;
                 for (int s = 0; s < 4; ++s)
                     wm.m[s] = L.ta[s].mag;
-                float2 *ydbg = dbg ? L.y : nullptr;
-                static const int nsrc = getenv("UMX_WIENER_NSRC") ? atoi(getenv("UMX_WIENER_NSRC")) : 4; // sources per workgroup (tuning knob)
-#define UMX_WI(W, NS)                                                                                                \
-    hipLaunchKernelGGL((wiener_istft_kernel<W, NS>), dim3(T, 4 / NS), dim3(256 * NS), (size_t)NS * FFT_LDS_ELEMS * sizeof(float2), st, \
-                       L.spec, wm, T, L.maxabs, L.Rc, window, nw, tw1, tw2, L.frames, ydbg)
-                const bool nowi = flags & UMX_FLAG_NO_WIENER;
-                if (nsrc == 1) { if (nowi) UMX_WI(false, 1); else UMX_WI(true, 1); }
-                else if (nsrc == 2) { if (nowi) UMX_WI(false, 2); else UMX_WI(true, 2); }
-                else { if (nowi) UMX_WI(false, 4); else UMX_WI(true, 4); }
-#undef UMX_WI
+                const size_t nel = (size_t)2 * T * NBINS;
+                hipLaunchKernelGGL(mixphase_kernel, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, L.spec, wm, T, L.y);
             }
+    }
+    else
+    {
+        static const int ns = getenv("UMX_WIENER_NS") ? atoi(getenv("UMX_WIENER_NS")) : 2; // sources per thread (measured: 4: 0.151, 2: 0.128, 1: 0.131 ms per track)
+        const dim3 g((NBINS + 63) / 64, nchunk * lanes.count, 4 / (ns == 1 || ns == 2 ? ns : 4));
+        if (ns == 1)
+            hipLaunchKernelGGL(wiener_stats4_kernel<1>, g, dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
+        else if (ns == 2)
+            hipLaunchKernelGGL(wiener_stats4_kernel<2>, g, dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
+        else
+            hipLaunchKernelGGL(wiener_stats4_kernel<4>, g, dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
+        hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4, lanes.count), dim3(256), 0, st, L0.wpart, T, L0.Rc, wiener_fused ? nullptr : L0.R, lanes, ls);
+        if (!wiener_fused)
+            for (int i = 0; i < lanes.count; ++i)
+            {
+                Lane &L = sl.lane[lanes.id[i]];
+                WienerMags wm;
+                for (int s = 0; s < 4; ++s)
+                    wm.m[s] = L.ta[s].mag;
+                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
+            }
+    }
+    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
+    if (!wiener_fused)
+    {
+        for (int i = 0; i < lanes.count; ++i)
+        {
+            Lane &L = sl.lane[lanes.id[i]];
+            hipLaunchKernelGGL(istft_frames_kernel, dim3(T, 4), dim3(256), 0, st, L.y, T, window, nw, tw1, tw2, L.frames);
         }
+    }
+    else
+    {
+        // gains + filter + inverse STFT frame in one pass (wiener_istft.h); y reaches HBM only for the debug tap
+        float2 *ydbg = dbg ? L0.y : nullptr;
+        static const int nsrc = getenv("UMX_WIENER_NSRC") ? atoi(getenv("UMX_WIENER_NSRC")) : 4; // sources per workgroup (tuning knob)
+#define UMX_WI(W, NS)                                                                                                \
+    hipLaunchKernelGGL((wiener_istft_kernel<W, NS>), dim3(T, 4 / NS, lanes.count), dim3(256 * NS), (size_t)NS * FFT_LDS_ELEMS * sizeof(float2), st, \
+                       L0.spec, wm0, T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, lanes, ls)
+        const bool nowi = flags & UMX_FLAG_NO_WIENER;
+        if (nsrc == 1) { if (nowi) UMX_WI(false, 1); else UMX_WI(true, 1); }
+        else if (nsrc == 2) { if (nowi) UMX_WI(false, 2); else UMX_WI(true, 2); }
+        else { if (nowi) UMX_WI(false, 4); else UMX_WI(true, 4); }
+#undef UMX_WI
+    }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
     if (sl.out_free_valid) // the stems this slot wrote two calls ago are still being downloaded from the same buffers
         UMX_HIP_CHECK(hipStreamWaitEvent(st, sl.out_free, 0));
-    for (int ln = 0; ln < nb; ++ln)
-        if (audio_dev[ln])
+    {
+        OlaOut oo;
+        oo.lanes = lanes;
+        int nmax = 1;
+        for (int i = 0; i < lanes.count; ++i)
         {
-            OlaOut oo;
+            const int ln = lanes.id[i];
             for (int s = 0; s < 4; ++s)
-                oo.p[s] = out[4 * ln + s];
-            hipLaunchKernelGGL(istft_ola_kernel, dim3((n[ln] + 255) / 256, 4), dim3(256), 0, st, sl.lane[ln].frames, T, n[ln], oo);
+                oo.p[i][s] = out[4 * ln + s];
+            oo.n[i] = n[ln];
+            nmax = std::max(nmax, n[ln]);
         }
+        hipLaunchKernelGGL(istft_ola_kernel, dim3((nmax + 255) / 256, 4, lanes.count), dim3(256), 0, st, L0.frames, ls.frames, T, oo);
+    }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_COUNT], st));
     UMX_HIP_CHECK(hipGetLastError());
     sl.have_times = true;

@@ -15,17 +15,29 @@
 namespace umx
 {
 
-// One workgroup per frame; both channels in one complex FFT.
-__global__ __launch_bounds__(256) void stft_kernel(const float *__restrict__ audio, int n, int N, int T,
+// One workgroup per frame; both channels in one complex FFT.  grid (T, lanes): entry blockIdx.y of `in`; spec, x and
+// maxabs_bits are lane 0's, lane l's sit l strides behind.
+struct StftIn
+{
+    const float *audio[MAX_TRACK_LANES]; // per entry of lanes
+    int n[MAX_TRACK_LANES];
+    LaneSet lanes;
+};
+__global__ __launch_bounds__(256) void stft_kernel(StftIn in, int N, int T,
                                                    const float *__restrict__ window,
                                                    const float2 *__restrict__ tw1,
                                                    const float2 *__restrict__ tw2,
-                                                   float2 *__restrict__ spec, float *__restrict__ x,
+                                                   float2 *__restrict__ spec, size_t spec_stride, float *__restrict__ x, size_t x_stride,
                                                    unsigned *__restrict__ maxabs_bits)
 {
     __shared__ float2 buf[FFT_LDS_ELEMS];
     __shared__ float red[4];
     const int f = blockIdx.x, j = threadIdx.x;
+    const int ln = in.lanes.id[blockIdx.y], n = in.n[blockIdx.y];
+    const float *__restrict__ audio = in.audio[blockIdx.y];
+    spec += (size_t)ln * spec_stride;
+    x += (size_t)ln * x_stride;
+    maxabs_bits += ln;
     const float2 *a2 = reinterpret_cast<const float2 *>(audio);
     float2 v[16];
 #pragma unroll
@@ -127,16 +139,19 @@ __global__ __launch_bounds__(256) void istft_frames_kernel(const float2 *__restr
 
 // Overlap-add in ascending frame order (the reference's fp32 summation order, dsp.cpp:237-257)
 // and crop [2048, 2048+n) (dsp.cpp:203-205).  out: 4 x (2,n) interleaved.  grid (ceil(n/256), 4).
+// grid (ceil(max n / 256), 4, lanes): entry blockIdx.z of `out`; frames is lane 0's.
 struct OlaOut
 {
-    float *p[4];
+    float *p[MAX_TRACK_LANES][4]; // per entry of lanes
+    int n[MAX_TRACK_LANES];
+    LaneSet lanes;
 };
-__global__ __launch_bounds__(256) void istft_ola_kernel(const float2 *__restrict__ frames, int T, int n,
-                                                        OlaOut out)
+__global__ __launch_bounds__(256) void istft_ola_kernel(const float2 *__restrict__ frames, size_t frames_stride, int T, OlaOut out)
 {
-    const int s = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y, n = out.n[blockIdx.z];
     if (s >= n)
         return;
+    frames += (size_t)out.lanes.id[blockIdx.z] * frames_stride;
     const int p = s + NFFT / 2;
     const int f_hi = min(T - 1, p / HOP);
     const int f_lo = p >= NFFT ? (p - NFFT) / HOP + 1 : 0;
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float2 *__restrict
         acc.x += c.x;
         acc.y += c.y;
     }
-    reinterpret_cast<float2 *>(out.p[src])[s] = acc;
+    reinterpret_cast<float2 *>(out.p[blockIdx.z][src])[s] = acc;
 }
 
 } // namespace umx

@@ -40,10 +40,22 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
                                                                   const float *__restrict__ Rc, const float *__restrict__ window,
                                                                   const float *__restrict__ nw, const float2 *__restrict__ tw1,
                                                                   const float2 *__restrict__ tw2, float2 *__restrict__ frames,
-                                                                  float2 *__restrict__ y_dbg)
+                                                                  float2 *__restrict__ y_dbg, LaneSet lanes, WienerStrides ls)
 {
     extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [NSRC][FFT_LDS_ELEMS]
     constexpr int WI_THREADS = 256 * NSRC;
+    {
+        const int ln = lanes.id[blockIdx.z]; // grid (T, 4 / NSRC, lanes): the pointers are lane 0's
+        spec += (size_t)ln * ls.spec;
+        Rc += (size_t)ln * ls.rc;
+        frames += (size_t)ln * ls.frames;
+        maxabs_bits += ln;
+        if (y_dbg)
+            y_dbg += (size_t)ln * ls.y;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            mags.m[s] += (size_t)ln * ls.mag;
+    }
     const int src0 = NSRC * blockIdx.y;
     const int f = blockIdx.x, tid = threadIdx.x;
     const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;

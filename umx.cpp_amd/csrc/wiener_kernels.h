@@ -169,13 +169,28 @@ __device__ __forceinline__ void wiener_frame_load(WienerFrame<NS> &w, const floa
 // per thread, the fewer times the mixture is read and its phasor formed; the fewer, the more waves to spread over the
 // chip: the accumulation is arithmetic- and latency-bound per wave).
 // part: [nchunk][4 sources][5][2049] = R00, Re R01, Im R01, R11, sum v (bin fastest)
+// Lanes: blockIdx.y = entry * nchunk + chunk; spec, mags, maxabs_bits and part are lane 0's (WienerStrides apart per lane).
+struct WienerStrides
+{
+    size_t spec, mag, part, rc, r8, frames, y; // elements between consecutive track lanes
+};
 template <int NS>
 __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
                                                            const unsigned *__restrict__ maxabs_bits,
-                                                           float *__restrict__ part)
+                                                           float *__restrict__ part, LaneSet lanes, WienerStrides ls)
 {
-    const int b = min(blockIdx.x * 64 + threadIdx.x, NBINS - 1), chunk = blockIdx.y; // surplus lanes repeat the last bin
+    const int nchunk_all = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
+    const int b = min(blockIdx.x * 64 + threadIdx.x, NBINS - 1), chunk = blockIdx.y % nchunk_all; // surplus lanes repeat the last bin
     const int s0 = NS * blockIdx.z;
+    {
+        const int ln = lanes.id[blockIdx.y / nchunk_all];
+        spec += (size_t)ln * ls.spec;
+        part += (size_t)ln * ls.part;
+        maxabs_bits += ln;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            mags.m[s] += (size_t)ln * ls.mag;
+    }
     const float max_abs = wiener_max_abs(maxabs_bits), rmax = 1.0f / max_abs;
     const int f0 = chunk * WIENER_CHUNK, f1 = min(T, f0 + WIENER_CHUNK);
     const float *mag[NS];
@@ -243,11 +258,18 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
 
 // grid (ceil(B/256), 4).  Rc: [4][2049][4] = {R00, Re R01, Im R01, R11}; R8 (optional): [4][2049][8]
 __global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__restrict__ part, int T, float *__restrict__ Rc,
-                                                             float *__restrict__ R8)
+                                                             float *__restrict__ R8, LaneSet lanes, WienerStrides ls)
 {
     const int b = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
     if (b >= NBINS)
         return;
+    {
+        const int ln = lanes.id[blockIdx.z]; // grid (ceil(B/256), 4, lanes)
+        part += (size_t)ln * ls.part;
+        Rc += (size_t)ln * ls.rc;
+        if (R8)
+            R8 += (size_t)ln * ls.r8;
+    }
     constexpr int CPB = WIENER_BATCH / WIENER_CHUNK;
     const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
