@@ -114,6 +114,35 @@ def test_gemm_tiles_that_straddle_track_lanes(pkg, po, tmp_path, flags):
         alone.close()
 
 
+def test_ping_pong_gemm_gives_the_bits_of_the_lock_step_kernel(pkg, tmp_path, monkeypatch):
+    """csrc/gemm_planes_pp.h (eight waves of 128 x 64 in two groups half a trip apart, the default for one-plane / u8
+    weights) against csrc/gemm_planes.h (sixteen waves of 64 x 64 in lock step): every accumulator sees the same
+    sequence of matrix instructions, so the stems, the carried state and every tap must agree bit for bit -- with the
+    ping-pong kernel forced on all four GEMMs (two-plane / u16 weights included: its half-tile phases), on none, and
+    as shipped.  Launches large enough for the 256 x 256 tiles in every GEMM (8 lanes x 900 frames, hidden 512)."""
+    H, N, B = 512, 900 * 1024, 8
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=47), H, compress=False)
+    waves = [[pkg.ggml.synth_audio(N - 333 * b, 1300 + 10 * b + s) for b in range(B)] for s in range(2)]
+    res = {}
+    for pp in ("15", "0", None):
+        if pp is None:
+            monkeypatch.delenv("UMX_GEMM_PP", raising=False)
+        else:
+            monkeypatch.setenv("UMX_GEMM_PP", pp)
+        eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
+        outs = [eng.infer_batch(w) for w in waves]
+        res[pp] = (outs, [eng.track_stream_get(b) for b in range(B)])
+        eng.close()
+    for pp in ("0", None):
+        for s in range(2):
+            for b in range(B):
+                for t in range(4):
+                    assert (res[pp][0][s][b][t] == res["15"][0][s][b][t]).all(), (pp, s, b, t)
+        for b in range(B):
+            assert (res[pp][1][b] == res["15"][1][b]).all(), (pp, b)
+
+
 def test_activation_planes_follow_the_data_range(pkg, po, tmp_path):
     """The plane GEMMs take every activation row as two fp16 planes of the row scaled by a power of two (csrc/gemm_planes.h):
     the scale follows the row, so a near-silent track (1e-5 of full scale, where a fixed-range fp16 split would be all

@@ -1732,7 +1732,7 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     // (gemm_planes_pp.h: same bits).  Measured alone, 32 lanes, ms per launch incl. the split kernel, A/B on one box (round 3):
     // fc1 5.70-5.98 -> 5.49-5.52, W_ih 5.69-6.14 -> 5.46-5.65, fc2 4.67-4.80 -> 4.76-4.96, fc3 9.00-9.20 -> 9.33-9.53:
     // ping-pong for the one-plane (u8) weights, lock step for the two-plane ones.  UMX_GEMM_PP: bit per GemmMode.
-    static const int gemm_pp = getenv("UMX_GEMM_PP") ? atoi(getenv("UMX_GEMM_PP")) : -1;
+    const int gemm_pp = getenv("UMX_GEMM_PP") ? atoi(getenv("UMX_GEMM_PP")) : -1; // read per launch: the tests switch it
     const bool pp = big && (gemm_pp < 0 ? nbp == 1 : ((gemm_pp >> mode) & 1));
 #define UMX_GP(MODE)                                                                                                 \
     if (pp && nbp == 1) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 1>), grid, dim3(512), lds, st, g);           \
