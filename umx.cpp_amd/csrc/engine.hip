@@ -1878,6 +1878,17 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
                 hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
             }
     }
+    OlaOut oo;
+    oo.lanes = lanes;
+    int nmax = 1;
+    for (int i = 0; i < lanes.count; ++i)
+    {
+        const int ln = lanes.id[i];
+        for (int s = 0; s < 4; ++s)
+            oo.p[i][s] = out[4 * ln + s];
+        oo.n[i] = n[ln];
+        nmax = std::max(nmax, n[ln]);
+    }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
     if (!wiener_fused)
     {
@@ -1889,33 +1900,31 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
     }
     else
     {
-        // gains + filter + inverse STFT frame in one pass (wiener_istft.h); y reaches HBM only for the debug tap
+        // gains + filter + inverse STFT frame + overlap-add in one pass (wiener_istft.h); y reaches HBM only for the debug
+        // tap, the frames only at the seams between the runs of frames the workgroups take
         float2 *ydbg = dbg ? L0.y : nullptr;
+        if (sl.out_free_valid) // the stems this slot wrote two calls ago are still being downloaded from the same buffers
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, sl.out_free, 0));
+        // runs: a few rounds of workgroups over the chip (one workgroup per CU), at least three frames each
+        const int runs = std::max(1, std::min(T / 8, (4 * n_cus + lanes.count - 1) / lanes.count));
+        const int run_len = std::max(3, (T + runs - 1) / runs), nruns = (T + run_len - 1) / run_len;
         static const int nsrc = getenv("UMX_WIENER_NSRC") ? atoi(getenv("UMX_WIENER_NSRC")) : 4; // sources per workgroup (tuning knob)
 #define UMX_WI(W, NS)                                                                                                \
-    hipLaunchKernelGGL((wiener_istft_kernel<W, NS>), dim3(T, 4 / NS, lanes.count), dim3(256 * NS), (size_t)NS * FFT_LDS_ELEMS * sizeof(float2), st, \
-                       L0.spec, wm0, T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, lanes, ls)
+    hipLaunchKernelGGL((wiener_istft_kernel<W, NS>), dim3(nruns, 4 / NS, lanes.count), dim3(256 * NS), (size_t)NS * FFT_LDS_ELEMS * sizeof(float2), st, \
+                       L0.spec, wm0, T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, ls, run_len, oo)
         const bool nowi = flags & UMX_FLAG_NO_WIENER;
         if (nsrc == 1) { if (nowi) UMX_WI(false, 1); else UMX_WI(true, 1); }
         else if (nsrc == 2) { if (nowi) UMX_WI(false, 2); else UMX_WI(true, 2); }
         else { if (nowi) UMX_WI(false, 4); else UMX_WI(true, 4); }
 #undef UMX_WI
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
+        hipLaunchKernelGGL(wiener_ola_edges_kernel, dim3(3 * HOP / 256, nruns * 4, lanes.count), dim3(256), 0, st, L0.frames, ls.frames, T, run_len, oo);
     }
-    UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
-    if (sl.out_free_valid) // the stems this slot wrote two calls ago are still being downloaded from the same buffers
-        UMX_HIP_CHECK(hipStreamWaitEvent(st, sl.out_free, 0));
+    if (!wiener_fused)
     {
-        OlaOut oo;
-        oo.lanes = lanes;
-        int nmax = 1;
-        for (int i = 0; i < lanes.count; ++i)
-        {
-            const int ln = lanes.id[i];
-            for (int s = 0; s < 4; ++s)
-                oo.p[i][s] = out[4 * ln + s];
-            oo.n[i] = n[ln];
-            nmax = std::max(nmax, n[ln]);
-        }
+        UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
+        if (sl.out_free_valid) // the stems this slot wrote two calls ago are still being downloaded from the same buffers
+            UMX_HIP_CHECK(hipStreamWaitEvent(st, sl.out_free, 0));
         hipLaunchKernelGGL(istft_ola_kernel, dim3((nmax + 255) / 256, 4, lanes.count), dim3(256), 0, st, L0.frames, ls.frames, T, oo);
     }
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_COUNT], st));

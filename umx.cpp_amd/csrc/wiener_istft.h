@@ -40,12 +40,13 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
                                                                   const float *__restrict__ Rc, const float *__restrict__ window,
                                                                   const float *__restrict__ nw, const float2 *__restrict__ tw1,
                                                                   const float2 *__restrict__ tw2, float2 *__restrict__ frames,
-                                                                  float2 *__restrict__ y_dbg, LaneSet lanes, WienerStrides ls)
+                                                                  float2 *__restrict__ y_dbg, WienerStrides ls, int run_len, OlaOut out)
 {
     extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [NSRC][FFT_LDS_ELEMS]
     constexpr int WI_THREADS = 256 * NSRC;
+    const LaneSet &lanes = out.lanes;
     {
-        const int ln = lanes.id[blockIdx.z]; // grid (T, 4 / NSRC, lanes): the pointers are lane 0's
+        const int ln = lanes.id[blockIdx.z]; // grid (runs of run_len frames, 4 / NSRC, lanes): the pointers are lane 0's
         spec += (size_t)ln * ls.spec;
         Rc += (size_t)ln * ls.rc;
         frames += (size_t)ln * ls.frames;
@@ -57,12 +58,23 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
             mags.m[s] += (size_t)ln * ls.mag;
     }
     const int src0 = NSRC * blockIdx.y;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;
+    const int f0 = (int)blockIdx.x * run_len, f1 = min(T, f0 + run_len);
+    const int g = tid >> 8; // source (of this workgroup's); j = tid & 255: thread of its transform
+    float2 *const stem = reinterpret_cast<float2 *>(out.p[blockIdx.z][src0 + g]);
+    const int n_out = out.n[blockIdx.z];
+    for (int f = f0; f < f1; ++f)
+    {
+    // the thread index is made opaque per frame: everything derived from it (a dozen 64-bit addresses per phase) is formed
+    // again where it is used instead of being carried across the phases of every frame (117 spilled registers otherwise)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int j = tl & 255;
 #pragma unroll
     for (int q = 0; q < (NFFT / 2 + WI_THREADS) / WI_THREADS; ++q)
     {
-        const int b = tid + WI_THREADS * q;
+        const int b = tl + WI_THREADS * q;
         if (b > NFFT / 2)
             break;
         const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
@@ -123,7 +135,6 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         }
     }
     __syncthreads();
-    const int g = tid >> 8, j = tid & 255; // source (of this workgroup's), thread of its transform
     float2 *buf = wi_buf + g * FFT_LDS_ELEMS;
     float2 v[16];
 #pragma unroll
@@ -131,8 +142,30 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         v[r] = buf[fft_pad(j + 256 * r)];
     __syncthreads();
     fft4096<true>(v, buf, tw1, tw2, j);
+    // ---- the frame's weighted samples: overlap-added on the way out.  Hop block h = samples [h HOP, (h + 1) HOP) of the
+    // padded signal is the sum of chunk h - f of the frames f = h - 3 .. h, in ascending f (dsp.cpp:237-257).  A workgroup
+    // takes its frames in that order, and a position is always the same thread's, so it adds straight into the stem
+    // (crop of dsp.cpp:203-205: sample p - 2048): chunk 3 is a block's first term and is written, chunks 0-2 are added to
+    // what the previous frames left (read past the L1: the line was written since it was last read).  Only the run's first
+    // three blocks also belong to the PREVIOUS run's last frames, whose terms come first: chunks that fall on them are kept
+    // in `frames` and added afterwards, in order, by wiener_ola_edges_kernel.  The 339 MB of frames per 60 s segment that the
+    // separate overlap-add kernel read back (and this kernel wrote) stay in the L2 / MALL as read-modify-writes of the stem.
     float2 *dst = frames + ((size_t)(src0 + g) * T + f) * NFFT;
     const size_t start = (size_t)f * HOP;
+    const bool keep = f - f0 < 3; // one of the run's first three frames
+    float2 prev[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) // chunks 0-2: what the earlier frames of this run left there
+    {
+        const int i = j + 256 * r, h = f + (r >> 2), s_out = (int)start + i - NFFT / 2;
+        prev[r] = make_float2(0.f, 0.f);
+        if (h >= f0 + 3 && s_out >= 0 && s_out < n_out)
+        {
+            // device-scope load: from the L2, where this thread's store of the previous frame went
+            const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(stem + s_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev[r] = make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
     {
@@ -140,8 +173,42 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         const float2 z = buf[fft_pad(i)];
         const float w = window[i];
         const float den = nw[start + i] + 1e-8f;
-        dst[i] = make_float2(z.x * w * 1.0f / float(NFFT) / den, z.y * w * 1.0f / float(NFFT) / den); // dsp.cpp:248-256
+        const float2 val = make_float2(z.x * w * 1.0f / float(NFFT) / den, z.y * w * 1.0f / float(NFFT) / den); // dsp.cpp:248-256
+        const int h = f + (r >> 2), s_out = (int)start + i - NFFT / 2;
+        if (keep)
+            dst[i] = val;
+        if (h >= f0 + 3 && s_out >= 0 && s_out < n_out)
+        {
+            const float2 a = r < 12 ? prev[r < 12 ? r : 0] : make_float2(0.f, 0.f); // chunk 3: the block's first term (0 + c)
+            stem[s_out] = make_float2(a.x + val.x, a.y + val.y);
+        }
     }
+    __syncthreads(); // the transforms' buffers are free for the next frame's gains; its reads of the stem follow these writes
+    }
+}
+
+// The first three hop blocks of every run of wiener_istft_kernel: the terms of the run's own frames (kept in `frames`)
+// are added to what the previous run's last frames left in the stem, in ascending frame order -- or to zero where no
+// earlier frame reaches (the start of the track).  grid (3 blocks x HOP / 256, runs x 4 sources, lanes).
+__global__ __launch_bounds__(256) void wiener_ola_edges_kernel(const float2 *__restrict__ frames, size_t frames_stride, int T, int run_len, OlaOut out)
+{
+    const int run = blockIdx.y >> 2, src = blockIdx.y & 3;
+    const int f0 = run * run_len, h = f0 + (int)(blockIdx.x * 256 + threadIdx.x) / HOP, k = (int)(blockIdx.x * 256 + threadIdx.x) % HOP;
+    const int s_out = h * HOP + k - NFFT / 2, n_out = out.n[blockIdx.z];
+    if (f0 >= T || s_out < 0 || s_out >= n_out)
+        return;
+    frames += (size_t)out.lanes.id[blockIdx.z] * frames_stride;
+    float2 *const stem = reinterpret_cast<float2 *>(out.p[blockIdx.z][src]);
+    const int fa = max(0, h - 3), fb = min(T - 1, h);
+    // frames before the run left their sum in the stem; f0 == first contributor: nothing was there
+    float2 acc = fa < f0 ? stem[s_out] : make_float2(0.f, 0.f);
+    for (int f = max(fa, f0); f <= fb; ++f)
+    {
+        const float2 c = frames[((size_t)src * T + f) * NFFT + (h - f) * HOP + k];
+        acc.x += c.x;
+        acc.y += c.y;
+    }
+    stem[s_out] = acc;
 }
 
 } // namespace umx
