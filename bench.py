@@ -75,7 +75,8 @@ def algorithmic_work(T, H):
         "ola": 4.0 * (4 * T * 4096 * 2 + 4 * 2 * T * 1024),
         # round-2 fused forms: all-source statistics (mixture + 4 magnitudes read once); gains + filter + inverse STFT frame
         "wiener_stats4": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB),
-        "wiener_istft": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * T * 4096 * 2),
+        # mixture + masks in, the STEMS out (the kernel overlap-adds: the frames no longer reach HBM)
+        "wiener_istft": 4.0 * (2 * T * NB * 2 + 4 * 2 * T * NB + 4 * 2 * T * 1024),
     }
     return gemm, rec, byt
 
@@ -354,8 +355,9 @@ def main():
         traffic = read_traffic(traffic_src) if traffic_src else {}
 
         def find_traffic(*needles):
+            # a needle may be a tuple of alternatives (the u8 GEMMs run as gemm_planes_pp_kernel, older CSVs hold gemm_planes_kernel)
             for kk, v in traffic.items():
-                if all(nd in kk for nd in needles):
+                if all(any(a in kk for a in (nd if isinstance(nd, tuple) else (nd,))) for nd in needles):
                     return v
             return None
 
@@ -386,8 +388,11 @@ def main():
         p8 = (2 if exact else 4) if flavour == "planes" else (3 if exact else 6)
         p16 = 4 if flavour == "planes" else 6
         # (the PMC summary holds demangled names: "void umx::gemm_planes_kernel<1, 1, 4, 4>(umx::GemmPArgs)" = <MODE, planes of B, WM, WN>)
-        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gname}<G_FC1>", (gname + "<0,",)),
-                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gname}<G_IH>", (gname + "<1,",)),
+        # one-plane (u8) weights: the ping-pong form of the plane GEMM (csrc/gemm_planes_pp.h), unless UMX_GEMM_PP says otherwise
+        pp = flavour == "planes" and exact and os.environ.get("UMX_GEMM_PP") is None and B * T >= 4096
+        g8 = "gemm_planes_pp_kernel" if pp else gname
+        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{g8}<G_FC1>", ((g8 + "<0,", gname + "<0,"),)),
+                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{g8}<G_IH>", ((g8 + "<1,", gname + "<1,"),)),
                    gemm_entry(["fc2"], "fc2", p16, f"{gname}<G_FC2>", (gname + "<2,",)),
                    gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{gname}<G_FC3>", (gname + "<3,",))]
         lstm_keys = [f"lstm_rec{l}" for l in range(3)]
@@ -427,11 +432,14 @@ def main():
                                 "hand-off floor (tools/handoff_probe.hip) / step time",
                         "traffic": find_traffic(("lstm_batch2" if B > 16 else "lstm_batch_kernel") if batched else "lstm_persistent")})
 
-        def stream_entry(key, name, nbytes, tneedle):
-            ms = stage_ms.get(key, 0.0) / B
-            ms_alone = stage_alone_ms.get(key, 0.0) / B
+        def stream_entry(key, name, nbytes, tneedle, per_lane_launches=False):
+            # the streaming kernels of a track-batched context cover every lane in one launch (common.h LaneSet)
+            nl = B if (per_lane_launches or not batched) else 1
+            nbytes = nbytes * (B // nl)
+            ms = stage_ms.get(key, 0.0) / nl
+            ms_alone = stage_alone_ms.get(key, 0.0) / nl
             ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            return {"kernel": name, "bound": "hbm", "launches_per_step": B, "launch_ms": round(ms, 4), "launch_ms_alone": round(ms_alone, 4),
+            return {"kernel": name, "bound": "hbm", "launches_per_step": nl, "launch_ms": round(ms, 4), "launch_ms_alone": round(ms_alone, 4),
                     "algorithmic_bytes_per_launch": nbytes, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4),
                     "frac_alone": round(nbytes / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_alone > 0 else None,
@@ -441,12 +449,12 @@ def main():
         if wmode == "fused":  # track-batched default: statistics, then gains + filter + inverse STFT frame in one kernel
             if not args.no_wiener:
                 kernels.append(stream_entry("wiener", "wiener_stats4_kernel (+ finish4)", byt["wiener_stats4"], "wiener_stats4"))
-            kernels.append(stream_entry("istft", "wiener_istft_kernel", byt["wiener_istft"], "wiener_istft"))
+            kernels.append(stream_entry("istft", "wiener_istft_kernel (filter + inverse STFT + overlap-add)", byt["wiener_istft"], "wiener_istft"))
         else:
             kernels += [stream_entry("wiener", "mixphase_kernel" if args.no_wiener else "wiener_{stats,finish,apply}_kernel (3 launches)",
-                                     byt["mixphase"] if args.no_wiener else byt["wiener"], "wiener_apply"),
-                        stream_entry("istft", "istft_frames_kernel", byt["istft"], "istft_frames")]
-        kernels.append(stream_entry("ola", "istft_ola_kernel", byt["ola"], "istft_ola"))
+                                     byt["mixphase"] if args.no_wiener else byt["wiener"], "wiener_apply", True),
+                        stream_entry("istft", "istft_frames_kernel", byt["istft"], "istft_frames", True)]
+            kernels.append(stream_entry("ola", "istft_ola_kernel", byt["ola"], "istft_ola"))
         # dominant = the largest share of a step by stand-alone time (the in-pipeline spans of the small per-track kernels
         # include whatever the other slot ran beside them)
         dominant = max(kernels, key=lambda kk: (kk["launch_ms_alone"] or kk["launch_ms"]) * kk["launches_per_step"])

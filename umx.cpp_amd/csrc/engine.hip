@@ -2011,6 +2011,13 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
         }
         pending.push_back(pc);
     }
+    // Track-batched contexts: the kernels of consecutive calls run one after the other.  Their workgroups take whole CUs (plane
+    // GEMM, batched LSTM, fused Wiener kernel), so kernels of two calls side by side only wait for each other's CUs: since the
+    // streaming kernels cover all lanes in one launch the serial step is the faster one (32 lanes: 75.4 against 76.3 ms).  The two
+    // slots remain for the buffers: uploads and downloads of neighbouring calls still overlap these kernels.  UMX_OVERLAP=1: as before.
+    static const bool overlap_calls = getenv("UMX_OVERLAP") && atoi(getenv("UMX_OVERLAP")) != 0;
+    if (lstm_batched && !overlap_calls && prev.used && &prev != &sl)
+        UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.ev[ST_COUNT], 0));
     if (int rc = stage_front(sl, st, nb, audio_dev, n, active, nact))
         return rc;
     // two LSTM grids at once only where both fit (the single-track kernel); otherwise wait for the previous

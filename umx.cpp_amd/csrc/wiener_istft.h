@@ -21,6 +21,10 @@
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
 
+#ifndef WI_STREAM_LOADS
+#define WI_STREAM_LOADS 1
+#endif
+
 namespace umx
 {
 
@@ -33,6 +37,15 @@ __device__ __forceinline__ float4 sel4(int s, const float4 (&r)[4])
     return make_float4(s == 0 ? r[0].x : s == 1 ? r[1].x : s == 2 ? r[2].x : r[3].x, s == 0 ? r[0].y : s == 1 ? r[1].y : s == 2 ? r[2].y : r[3].y,
                        s == 0 ? r[0].z : s == 1 ? r[1].z : s == 2 ? r[2].z : r[3].z, s == 0 ? r[0].w : s == 1 ? r[1].w : s == 2 ? r[2].w : r[3].w);
 }
+
+// streamed-once inputs: non-temporal loads, so that they do not push the stems' read-modify-write lines out of the L2
+typedef float wi_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ld_stream(const float2 *p)
+{
+    const wi_f2 v = __builtin_nontemporal_load(reinterpret_cast<const wi_f2 *>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
 
 template <bool WIENER, int NSRC>
 __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
@@ -79,14 +92,14 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
             break;
         const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
         const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
-        const float2 X0 = spec[i0], X1 = spec[i1];
+        const float2 X0 = WI_STREAM_LOADS ? ld_stream(spec + i0) : spec[i0], X1 = WI_STREAM_LOADS ? ld_stream(spec + i1) : spec[i1];
         const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
         float m0[4], m1[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            m0[s] = mags.m[s][j0] * h0; // target magnitude = mask x |X| (inference.cpp:175-183)
-            m1[s] = mags.m[s][j1] * h1;
+            m0[s] = (WI_STREAM_LOADS ? ld_stream(mags.m[s] + j0) : mags.m[s][j0]) * h0; // target magnitude = mask x |X| (inference.cpp:175-183)
+            m1[s] = (WI_STREAM_LOADS ? ld_stream(mags.m[s] + j1) : mags.m[s][j1]) * h1;
         }
         WienerBin wb;
         float4 rc[4];
