@@ -313,7 +313,7 @@ struct umx_hip_ctx
     };
     int queue_download(const DeferredDownload &d, hipStream_t on); // D2H copies of d onto stream `on`, then out_free of its slot
     hipStream_t copy_stream = nullptr; // downloads of the host-pointer calls (created with the staging buffers)
-    float *state = nullptr;
+    float *state = nullptr, *state_alt = nullptr; // state_alt: second copy for the per-step driver of the batched recurrence
     Slot slot[kMaxSlots];
     int nslots = 2; // pipeline slots: 3 for single-track contexts (see init), 2 for track-batched ones
     int next_slot() const { return (int)(nseg % nslots); }
@@ -1068,6 +1068,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             return rc;
     if (int rc = dalloc(&state, state_floats() * B))
         return rc;
+    if (int rc = dalloc(&state_alt, state_floats() * B))
+        return rc;
     if (int rc = dalloc(&backup, (size_t)kBackupCalls * 3 * state_floats() * B))
         return rc;
     lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) * ((B + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS) : (size_t)0);
@@ -1459,6 +1461,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     }
     a.bhh = bhh[layer];
     a.state = state;
+    a.state_out = state;
     a.state_stride = state_floats();
     a.sync = sl.lsync;
     a.status = sl.status;
@@ -1517,12 +1520,23 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     {
         a.census = 0;
         a.abort_at = 0;
+        // One step per launch, h / c carried through the fp32 stream state.  Every workgroup reads the h of its whole chain at
+        // the start of a launch and writes its own units at the end, so a launch must not update the copy it reads: the
+        // workgroups of a grid do not start together (round 3: one GPU-suite run in nine failed the per-step bitwise test at
+        // 20 lanes; rounds 2-3 updated `state` in place).  This layer's entries ping-pong between `state` and `state_alt`
+        // (rows = lanes x targets, 4 Hl floats of every 12 Hl: the other layers' entries may be in use by another slot).
+        const size_t row = (size_t)4 * Hl * sizeof(float), pitch = 3 * row, off = (size_t)layer * 4 * Hl;
+        UMX_HIP_CHECK(hipMemcpy2DAsync(state_alt + off, pitch, state + off, pitch, row, (size_t)4 * B, hipMemcpyDeviceToDevice, st));
         for (int step = 0; step < T; ++step)
         {
             a.t_begin = step;
             a.t_end = step + 1;
+            a.state = (step & 1) ? state_alt : state;
+            a.state_out = (step & 1) ? state : state_alt;
             UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * S), dim3(threads), kargs, lds, st));
         }
+        if (T & 1) // the last launch wrote state_alt
+            UMX_HIP_CHECK(hipMemcpy2DAsync(state + off, pitch, state_alt + off, pitch, row, (size_t)4 * B, hipMemcpyDeviceToDevice, st));
     }
     sl.last_persistent = persistent;
     UMX_HIP_CHECK(hipGetLastError());

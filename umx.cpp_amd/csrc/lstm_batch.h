@@ -76,6 +76,10 @@ struct LstmBArgs
     const float *P[4];       // track lane n of target i: P[i] + n * p_stride
     float *out[4];           // out[i] + n * out_stride + t*ldo + col0 + dir*Hl + unit
     float *state;            // lane n: state + n * state_stride, then [4 targets][3 layers][2 dirs][2 (h,c)][Hl]
+    float *state_out;        // where the launch leaves h / c: `state` itself for a launch that covers the whole segment; the OTHER
+                             // of two copies for the one-step launches of the per-step driver -- a workgroup reads the h of its whole
+                             // chain when it starts and writes its own 16 units when it ends, and nothing keeps a late workgroup
+                             // of a launch from starting after an early one has finished
     size_t p_stride, out_stride, state_stride;
     unsigned *sync;          // [0..7] census, [8] arrivals, [LSTM_SYNC_HEADER_WORDS..] granules u64 [2][8][Hl/8][16][8]
     unsigned *status;
@@ -565,8 +569,8 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
         if (t_end > t_begin)
             outp[(size_t)(dir == 0 ? t_end - 1 : T - t_end) * ldo] = hlast;
 #endif
-        a.state[st_h + unit] = hlast;
-        a.state[st_c + unit] = c;
+        a.state_out[st_h + unit] = hlast;
+        a.state_out[st_c + unit] = c;
     }
     if (prof && l == 0)
     {

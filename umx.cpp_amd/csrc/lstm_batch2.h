@@ -308,8 +308,8 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
             {
                 if (t_end > t_begin)
                     outp[(size_t)(NB * g) * a.out_stride + (size_t)(dir == 0 ? t_end - 1 : T - t_end) * ldo] = hlast[g];
-                a.state[st_h[g] + unit] = hlast[g];
-                a.state[st_c[g] + unit] = c[g];
+                a.state_out[st_h[g] + unit] = hlast[g];
+                a.state_out[st_c[g] + unit] = c[g];
             }
 }
 
