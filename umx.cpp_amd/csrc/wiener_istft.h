@@ -21,6 +21,9 @@
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
 
+#ifndef WI_PROFILE
+#define WI_PROFILE 0 // 1: one workgroup per launch prints where the cycles of a frame go (timing build)
+#endif
 #ifndef WI_STREAM_LOADS
 #define WI_STREAM_LOADS 1
 #endif
@@ -77,8 +80,12 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
     const int g = tid >> 8; // source (of this workgroup's); j = tid & 255: thread of its transform
     float2 *const stem = reinterpret_cast<float2 *>(out.p[blockIdx.z][src0 + g]);
     const int n_out = out.n[blockIdx.z];
+    [[maybe_unused]] long long pf[5] = {0, 0, 0, 0, 0};
     for (int f = f0; f < f1; ++f)
     {
+    [[maybe_unused]] long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    if (WI_PROFILE)
+        c0 = clock64();
     // the thread index is made opaque per frame: everything derived from it (a dozen 64-bit addresses per phase) is formed
     // again where it is used instead of being carried across the phases of every frame (117 spilled registers otherwise)
     int tl = tid;
@@ -147,7 +154,11 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
                 buf[fft_pad(NFFT - b)] = make_float2(a.x + bb.y, bb.x - a.y); // conj(a) + i conj(b)
         }
     }
+    if (WI_PROFILE)
+        c1 = clock64();
     __syncthreads();
+    if (WI_PROFILE)
+        c2 = clock64();
     float2 *buf = wi_buf + g * FFT_LDS_ELEMS;
     float2 v[16];
 #pragma unroll
@@ -155,6 +166,8 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         v[r] = buf[fft_pad(j + 256 * r)];
     __syncthreads();
     fft4096<true>(v, buf, tw1, tw2, j);
+    if (WI_PROFILE)
+        c3 = clock64();
     // ---- the frame's weighted samples: overlap-added on the way out.  Hop block h = samples [h HOP, (h + 1) HOP) of the
     // padded signal is the sum of chunk h - f of the frames f = h - 3 .. h, in ascending f (dsp.cpp:237-257).  A workgroup
     // takes its frames in that order, and a position is always the same thread's, so it adds straight into the stem
@@ -167,6 +180,7 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
     const size_t start = (size_t)f * HOP;
     const bool keep = f - f0 < 3; // one of the run's first three frames
     float2 prev[12];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's stores of the previous frame (same addresses) are in the L2
 #pragma unroll
     for (int r = 0; r < 12; ++r) // chunks 0-2: what the earlier frames of this run left there
     {
@@ -186,7 +200,12 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         const float2 z = buf[fft_pad(i)];
         const float w = window[i];
         const float den = nw[start + i] + 1e-8f;
-        const float2 val = make_float2(z.x * w * 1.0f / float(NFFT) / den, z.y * w * 1.0f / float(NFFT) / den); // dsp.cpp:248-256
+        // dsp.cpp:248-256: frame * w * 1.0f / 4096 / (nw + 1e-8f), in that order.  The division by 4096 is an exact scaling; the one
+        // by den (shared by both channels) as reciprocal + exact-remainder correction (div_by, common.h: the correctly rounded
+        // quotient, the bits of the IEEE division istft_frames_kernel performs -- the fused-vs-unfused test compares them):
+        // 7 instead of 22 instructions per sample in a kernel that is bound by its VALU instructions (WI_PROFILE)
+        const float rden = __builtin_amdgcn_rcpf(den);
+        const float2 val = make_float2(div_by(z.x * w * 1.0f / float(NFFT), den, rden), div_by(z.y * w * 1.0f / float(NFFT), den, rden));
         const int h = f + (r >> 2), s_out = (int)start + i - NFFT / 2;
         if (keep)
             dst[i] = val;
@@ -196,8 +215,22 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
             stem[s_out] = make_float2(a.x + val.x, a.y + val.y);
         }
     }
-    __syncthreads(); // the transforms' buffers are free for the next frame's gains; its reads of the stem follow these writes
+    // the transforms' buffers are free for the next frame's gains: an LDS-only barrier -- __syncthreads() would also wait for the
+    // acknowledgements of this frame's stores (vmcnt(0)) with every wave idle; the next frame waits for them where it reads the
+    // stem again, two phases later, when they have long arrived
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (WI_PROFILE)
+    {
+        c4 = clock64();
+        pf[0] += c1 - c0;
+        pf[1] += c2 - c1;
+        pf[2] += c3 - c2;
+        pf[3] += c4 - c3;
     }
+    }
+    if (WI_PROFILE && blockIdx.x == 7 && blockIdx.z == 3 && (tid == 0 || tid == 777))
+        printf("# wiener_istft thread %d, %d frames: cycles per frame  loads+gains %lld  barrier %lld  transform %lld  weight+overlap-add+drain %lld\n", tid,
+               f1 - f0, pf[0] / (f1 - f0), pf[1] / (f1 - f0), pf[2] / (f1 - f0), pf[3] / (f1 - f0));
 }
 
 // The first three hop blocks of every run of wiener_istft_kernel: the terms of the run's own frames (kept in `frames`)
