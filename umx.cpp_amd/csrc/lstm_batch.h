@@ -40,6 +40,7 @@
 namespace umx
 {
 
+static_assert(MAX_TRACK_LANES == 48, "common.h LaneSet covers every track lane of a context");
 constexpr int LSTMB_MAX_TRACKS = 48;  // track lanes per context: 16 per launch of this kernel, two or three groups of 16 in lstm_batch2.h
 constexpr int LSTMB_GROUP_TRACKS = 16; // the matrix instruction's N
 // x64 shader cycles a wave sleeps before its first poll of a step.  A wave that also runs the gate phase has just
