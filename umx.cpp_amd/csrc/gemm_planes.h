@@ -217,19 +217,17 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_kernel(S
     }
 }
 
-// MI = 32-row matrix tiles per wave along M (2: wave tile 64 x 64, the 16-wave form of the 256 x 256 block; 4: wave tile
-// 128 x 64, EIGHT waves of up to 256 registers for the same block -- 10 instead of 12 fragment reads per 16 matrix
-// instructions, half as many parties at the barrier; round 3, profiles/r03_gemm_pace_experiments.txt).  Every accumulator
-// sees the same sequence of matrix instructions in either form: the results are bit-identical.  Worth 1-3 % on the u8
-// GEMMs, nothing on the u16 ones: the trip's pace is the matrix pipe's at the clock the chip holds under this load.
-template <int MODE, int NBP, int WM, int WN, int MI = 2>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN * MI >= 32) ? 1 : 2) void gemm_planes_kernel(GemmPArgs args)
+// Wave tile 64 x 64 (MI = 2 matrix tiles of 32 rows along M): sixteen waves per 256 x 256 block, all in lock step on one
+// barrier per K tile.  The eight-wave 128 x 64 form of round 3 lives on as gemm_planes_pp.h, where the two waves of a SIMD take
+// turns at the matrix pipe (the default for one-plane weights); both give the bits of this kernel.
+template <int MODE, int NBP, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_planes_kernel(GemmPArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];
+    constexpr int MI = 2;
     constexpr int BM = 32 * MI * WM, BN = 64 * WN, NW = WM * WN;
     constexpr int A_PL = BM * 64, B_PL = BN * 64; // bytes of one plane tile of each operand
     constexpr int BUF_BYTES = 2 * A_PL + NBP * B_PL, STAGES = gp_stages(BM / 64, WN, NBP);
-    static_assert(MI == 2 || MI == 4, "wave tile 64 x 64 or 128 x 64");
     static_assert(NBP == 1 || NBP == 2, "weight planes: 1 (u8) or 2 (u16, fp32)");
     const GemmPTarget tg = args.t[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
