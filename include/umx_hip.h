@@ -166,7 +166,10 @@ int umx_hip_infer_segment_async(umx_hip_ctx *ctx, const float *audio_host, int n
  * CONSECUTIVE calls must be given DISTINCT out_dev buffers (that many segments are in flight together); (3) work the caller queued on a stream
  * of its own that produces audio_dev is ordered in front of the next call with umx_hip_order_after.
  * A caller that fences with umx_hip_order_before (and then recycles its buffers) gives up the timeout recovery for the
- * calls queued so far: a persistent-kernel timeout among them is reported as UMX_ERR_TIMEOUT by the next umx_hip_sync. */
+ * calls queued so far: a persistent-kernel timeout among them is reported as UMX_ERR_TIMEOUT by the next umx_hip_sync.
+ * Track-batched contexts (umx_hip_create_tracks with more than one lane) run the KERNELS of consecutive calls one after the
+ * other (their workgroups take whole CUs: side by side they only wait for each other); the slots' streams still let a
+ * call's uploads and downloads run beside another call's kernels, and the contract above is unchanged. */
 int umx_hip_infer_segment_device(umx_hip_ctx *ctx, const float *audio_dev, int n, float *const out_dev[4],
                                  unsigned flags);
 /* One segment of each of n_tracks track lanes (lane i = the i-th track of the context, its LSTM state carries from
