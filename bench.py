@@ -388,13 +388,13 @@ def main():
         p8 = (2 if exact else 4) if flavour == "planes" else (3 if exact else 6)
         p16 = 4 if flavour == "planes" else 6
         # (the PMC summary holds demangled names: "void umx::gemm_planes_kernel<1, 1, 4, 4>(umx::GemmPArgs)" = <MODE, planes of B, WM, WN>)
-        # one-plane (u8) weights: the ping-pong form of the plane GEMM (csrc/gemm_planes_pp.h), unless UMX_GEMM_PP says otherwise
-        pp = flavour == "planes" and exact and os.environ.get("UMX_GEMM_PP") is None and B * T >= 4096
+        # 256 x 256 launches run the ping-pong form of the plane GEMM (csrc/gemm_planes_pp.h), unless UMX_GEMM_PP says otherwise
+        pp = flavour == "planes" and os.environ.get("UMX_GEMM_PP") is None and B * T >= 4096
         g8 = "gemm_planes_pp_kernel" if pp else gname
         kernels = [gemm_entry(["fc1"], "fc1", p8, f"{g8}<G_FC1>", ((g8 + "<0,", gname + "<0,"),)),
                    gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{g8}<G_IH>", ((g8 + "<1,", gname + "<1,"),)),
-                   gemm_entry(["fc2"], "fc2", p16, f"{gname}<G_FC2>", (gname + "<2,",)),
-                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{gname}<G_FC3>", (gname + "<3,",))]
+                   gemm_entry(["fc2"], "fc2", p16, f"{g8}<G_FC2>", ((g8 + "<2,", gname + "<2,"),)),
+                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{g8}<G_FC3>", ((g8 + "<3,", gname + "<3,"),))]
         lstm_keys = [f"lstm_rec{l}" for l in range(3)]
         lms = sum(stage_ms.get(kk, 0.0) for kk in lstm_keys) / 3
         lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3

@@ -119,7 +119,7 @@ def test_ping_pong_gemm_gives_the_bits_of_the_lock_step_kernel(pkg, tmp_path, mo
     weights) against csrc/gemm_planes.h (sixteen waves of 64 x 64 in lock step): every accumulator sees the same
     sequence of matrix instructions, so the stems, the carried state and every tap must agree bit for bit -- with the
     ping-pong kernel forced on all four GEMMs (two-plane / u16 weights included: its half-tile phases), on none, and
-    as shipped.  Launches large enough for the 256 x 256 tiles in every GEMM (8 lanes x 900 frames, hidden 512)."""
+    as shipped (= all four since the end of round 3).  Launches large enough for the 256 x 256 tiles in every GEMM (8 lanes x 900 frames, hidden 512)."""
     H, N, B = 512, 900 * 1024, 8
     path = str(tmp_path / "m.bin")
     pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=47), H, compress=False)

@@ -1742,12 +1742,11 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     const int bm = big ? 256 : 128;
     const dim3 grid((unsigned)round_up((g.N / bm) * (g.M / bm), 8), 1, nact), block(big ? 1024 : 256);
     const size_t lds = big ? gp_lds_bytes(4, 4, nbp) : gp_lds_bytes(2, 2, nbp);
-    // 256 x 256 blocks: 16 waves of 64 x 64 in lock step (gemm_planes.h), or eight waves of 128 x 64 in ping-pong
-    // (gemm_planes_pp.h: same bits).  Measured alone, 32 lanes, ms per launch incl. the split kernel, A/B on one box (round 3):
-    // fc1 5.70-5.98 -> 5.49-5.52, W_ih 5.69-6.14 -> 5.46-5.65, fc2 4.67-4.80 -> 4.76-4.96, fc3 9.00-9.20 -> 9.33-9.53:
-    // ping-pong for the one-plane (u8) weights, lock step for the two-plane ones.  UMX_GEMM_PP: bit per GemmMode.
+    // 256 x 256 blocks: eight waves of 128 x 64 in ping-pong (gemm_planes_pp.h), or sixteen waves of 64 x 64 in lock step
+    // (gemm_planes.h: same bits; UMX_GEMM_PP=0, or a bit per GemmMode).  Measured alone, 32 lanes, ms per launch incl. the split
+    // kernel, A/B on one box (round 3): fc1 5.70-5.98 -> 5.38-5.52, W_ih 5.69-6.14 -> 5.29-5.67, fc2 4.77 -> 4.62-4.66, fc3 9.21 -> 8.98-9.15.
     const int gemm_pp = getenv("UMX_GEMM_PP") ? atoi(getenv("UMX_GEMM_PP")) : -1; // read per launch: the tests switch it
-    const bool pp = big && (gemm_pp < 0 ? nbp == 1 : ((gemm_pp >> mode) & 1));
+    const bool pp = big && (gemm_pp < 0 || ((gemm_pp >> mode) & 1));
 #define UMX_GP(MODE)                                                                                                 \
     if (pp && nbp == 1) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 1>), grid, dim3(512), lds, st, g);           \
     else if (pp) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 2>), grid, dim3(512), lds, st, g);                  \

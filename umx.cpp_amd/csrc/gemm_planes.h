@@ -219,7 +219,8 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_kernel(S
 
 // Wave tile 64 x 64 (MI = 2 matrix tiles of 32 rows along M): sixteen waves per 256 x 256 block, all in lock step on one
 // barrier per K tile.  The eight-wave 128 x 64 form of round 3 lives on as gemm_planes_pp.h, where the two waves of a SIMD take
-// turns at the matrix pipe (the default for one-plane weights); both give the bits of this kernel.
+// turns at the matrix pipe: the default for every 256 x 256 launch (UMX_GEMM_PP=0 selects this kernel); it gives the bits of this
+// kernel, which stays the only form for the 128 x 128 tiles of small launches.
 template <int MODE, int NBP, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_planes_kernel(GemmPArgs args)
 {

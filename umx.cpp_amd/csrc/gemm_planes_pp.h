@@ -14,9 +14,8 @@
 //
 // so that at any time one wave of a SIMD owns the matrix pipe while the other reads the fragments of its next unit
 // (20 KB per wave: 640 cycles of the LDS port for the four reading waves against 1,024 cycles of matrix instructions).
-// A unit is a whole 32-k tile for one-plane (u8) weights and a 16-k half tile for two-plane (u16) weights: 32 matrix
-// instructions and at most 80 fragment registers either way, beside the 128 accumulator registers of the 128 x 64 wave
-// tile.  Group 0 issues all LDS-DMA (in its M phase, into the stage both groups finished reading one barrier ago) and
+// A unit is a whole 32-k tile: 32 matrix instructions and 80 fragment registers for one-plane (u8) weights, 64 and 96 for
+// two-plane (u16) ones, beside the 128 accumulator registers of the 128 x 64 wave tile.  Group 0 issues all LDS-DMA (in its M phase, into the stage both groups finished reading one barrier ago) and
 // waits for a tile at the end of the C phase before the M phase that reads it: a tile has two trips to arrive, as in
 // gemm_planes_kernel.  Every accumulator sees the same sequence of matrix instructions as there: bit-identical results.
 #pragma once
@@ -31,7 +30,9 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
     constexpr int MI = 4, BM = 256, BN = 256;
     constexpr int A_PL = BM * 64, B_PL = BN * 64; // bytes of one plane tile of each operand
     constexpr int BUF_BYTES = 2 * A_PL + NBP * B_PL, STAGES = gp_stages(4, 4, NBP);
-    constexpr int PH = NBP, KKP = 2 / PH; // phases per K tile, 16-k steps per phase
+    constexpr int PH = 1, KKP = 2 / PH; // phases per K tile, 16-k steps per phase (half-tile phases for the two-plane weights
+                                        // -- 32 matrix instructions per phase like the one-plane form -- measured slower: four
+                                        // barriers per trip; fc2 4.9 against 4.6 ms, fc3 9.4 against 9.0)
     static_assert(NBP == 1 || NBP == 2, "weight planes: 1 (u8) or 2 (u16, fp32)");
     const GemmPTarget tg = args.t[blockIdx.z];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
