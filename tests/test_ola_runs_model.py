@@ -1,0 +1,86 @@
+"""The overlap-add schedule of the fused Wiener / inverse-STFT kernel (umx.cpp_amd/csrc/wiener_istft.h), restated in numpy
+float32 and checked bit for bit against the reference's order (dsp.cpp:237-257: every output sample is the sum of the
+frames that cover it, added in ascending frame order, then cropped by 2048 samples, dsp.cpp:203-205).
+
+The device kernel gives every workgroup a RUN of consecutive frames.  A frame's four hop-sized chunks land on the hop blocks
+f .. f + 3 of the padded signal; inside a run, chunk 3 is a block's first term (written as 0 + c) and chunks 0-2 are added to
+what the run's earlier frames left.  The first three blocks of a run also belong to the previous run's last frames, whose terms
+must come first: the run keeps its first three frames and `wiener_ola_edges_kernel` adds their chunks to those blocks afterwards,
+in frame order.  This model runs the runs in an arbitrary order (workgroups are not ordered on the device) and must still give
+the reference's bits; the GPU test of the kernel itself is tests/test_gpu_parity.py::test_fused_wiener_istft_equals_...
+"""
+import numpy as np
+import pytest
+
+HOP, NFFT = 1024, 4096
+
+
+def reference_ola(frames, n):
+    """dsp.cpp:237-257 + crop: out[s] = sum over f (ascending) of frames[f][s + 2048 - f * HOP]."""
+    T = frames.shape[0]
+    acc = np.zeros((T + 3) * HOP, np.float32)
+    for f in range(T):  # ascending frame order = the order every sample's terms are added in
+        acc[f * HOP:f * HOP + NFFT] = acc[f * HOP:f * HOP + NFFT] + frames[f]
+    return acc[NFFT // 2:NFFT // 2 + n].copy()
+
+
+def fused_ola(frames, n, run_len, rng):
+    T = frames.shape[0]
+    assert run_len >= 3  # engine.hip: a run that is not the last one has at least three frames
+    stem = rng.standard_normal(n).astype(np.float32)  # whatever the buffer held before: must not matter
+    kept = {}
+    runs = [(f0, min(T, f0 + run_len)) for f0 in range(0, T, run_len)]
+
+    def put(h, values, first):
+        lo, hi = h * HOP - NFFT // 2, (h + 1) * HOP - NFFT // 2  # stem samples of hop block h
+        a, b = max(lo, 0), min(hi, n)
+        if a >= b:
+            return
+        v = values[a - lo:b - lo]
+        stem[a:b] = (np.float32(0) + v) if first else (stem[a:b] + v)
+
+    for i in rng.permutation(len(runs)):  # workgroups run in no particular order
+        f0, f1 = runs[i]
+        for f in range(f0, f1):  # ... but a workgroup takes its frames in order
+            if f - f0 < 3:
+                kept[f] = frames[f]
+            for c in range(4):
+                h = f + c
+                if h >= f0 + 3:  # the block is this run's alone from here on
+                    put(h, frames[f][c * HOP:(c + 1) * HOP], first=(c == 3))
+    for f0, _ in runs:  # wiener_ola_edges_kernel, after the main kernel
+        for h in range(f0, f0 + 3):
+            lo, hi = h * HOP - NFFT // 2, (h + 1) * HOP - NFFT // 2
+            a, b = max(lo, 0), min(hi, n)
+            if a >= b:
+                continue
+            fa, fb = max(0, h - 3), min(T - 1, h)
+            acc = stem[a:b].copy() if fa < f0 else np.zeros(b - a, np.float32)
+            for f in range(max(fa, f0), fb + 1):
+                acc = acc + kept[f][(h - f) * HOP + a - lo:(h - f) * HOP + b - lo]
+            stem[a:b] = acc
+    return stem
+
+
+@pytest.mark.parametrize("T,run_len", [(5, 5), (5, 3), (26, 3), (26, 4), (26, 7), (26, 81), (97, 13), (97, 96)])
+def test_run_wise_overlap_add_has_the_bits_of_the_reference_order(T, run_len):
+    rng = np.random.default_rng(1000 * T + run_len)
+    # terms of very different magnitude, so that the order of the additions shows in the bits
+    frames = (rng.standard_normal((T, NFFT)) * np.exp(rng.uniform(-12, 4, (T, NFFT)))).astype(np.float32)
+    N = (T - 1) * HOP  # dsp.hpp:48: T = N / HOP + 1
+    for n in (N, N - 777, max(1, N - 3 * HOP - 5), 1):
+        ref = reference_ola(frames, n)
+        got = fused_ola(frames, n, run_len, rng)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (T, run_len, n)
+
+
+def test_a_different_order_of_the_terms_would_show():
+    """The check above can fail: adding a block's terms in descending frame order changes bits."""
+    rng = np.random.default_rng(7)
+    T = 26
+    frames = (rng.standard_normal((T, NFFT)) * np.exp(rng.uniform(-12, 4, (T, NFFT)))).astype(np.float32)
+    n = (T - 1) * HOP
+    acc = np.zeros((T + 3) * HOP, np.float32)
+    for f in reversed(range(T)):
+        acc[f * HOP:f * HOP + NFFT] = acc[f * HOP:f * HOP + NFFT] + frames[f]
+    assert not np.array_equal(acc[NFFT // 2:NFFT // 2 + n].view(np.uint32), reference_ola(frames, n).view(np.uint32))
