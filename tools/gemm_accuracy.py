@@ -6,8 +6,8 @@ reference would use (fl(q*scale+offset), model.cpp:610-616):
   fc1 -> bn1 -> tanh       K = 2974, u8 weights      [planes: exact one-plane weights, 3 products, affine map on the sum]
   fc2 -> bn2 -> relu       K = 2048, u16 weights     [planes: exact two-plane weights, 5 products]
   3-layer BiLSTM           2584-step-class recurrence, u8 W_hh, from the engine's fc1 output (torch float64 LSTM)
-for the GEMM flavours planes / bf16x3 (staged split) / f32 MFMA, the single-track (VALU) and the batched (matrix-core)
-LSTM kernels, and the CPU oracle (fp32)."""
+for the GEMM flavours planes / bf16x3 (staged split), the single-track (VALU) and the batched (matrix-core) LSTM kernels, and the
+CPU oracle (fp32).  (The fp32-MFMA flavour of rounds 1-2 is gone; its figures are in profiles/r02_accuracy_vs_float64.txt.)"""
 import sys
 import tempfile
 from pathlib import Path
@@ -82,10 +82,10 @@ for t in (0, 3):
     lstm.load_state_dict({f"{wn}_l{l}{sfx}": torch.from_numpy(g(t, f"lstm.{wn}_l{l}{sfx}").reshape(targets[t][f"lstm.{wn}_l{l}{sfx}"]["f32"].shape))
                           for l in range(3) for sfx in ("", "_reverse") for wn in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")})
     with torch.no_grad():
-        for name in ("planes", "planes+batched LSTM", "f32 MFMA"):
+        for name in ("planes", "planes+batched LSTM"):
             want = lstm(torch.from_numpy(res[name]["fc1"][t].astype(np.float64))[:, None, :])[0][:, 0].numpy()
             report("lstm", name + (" (VALU kernel)" if name == "planes" else ""), res[name]["lstm"][t], want)
         want = lstm(torch.from_numpy(oracle["fc1"][t].astype(np.float64))[:, None, :])[0][:, 0].numpy()
         report("lstm", "CPU oracle (fp32)", oracle["lstm"][t], want)
-print("end-to-end mask, planes vs f32 MFMA: max abs",
-      max(float(np.abs(res['planes']['mask'][t] - res['f32 MFMA']['mask'][t]).max()) for t in range(4)))
+print("end-to-end mask, planes vs bf16x3: max abs",
+      max(float(np.abs(res['planes']['mask'][t] - res['bf16x3']['mask'][t]).max()) for t in range(4)))
