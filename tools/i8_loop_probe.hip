@@ -124,6 +124,12 @@ __global__ __launch_bounds__(512, 1) void i8_loop_kernel(const signed char *A, c
 #ifndef PROBE_LOCKSTEP
 #define PROBE_LOCKSTEP 0 // 1: all eight waves in one phase, one barrier per trip (gemm_planes.h's schedule) instead of ping-pong
 #endif
+#ifndef PROBE_NOWAIT
+#define PROBE_NOWAIT 0 // 1: the staging is issued but never waited for inside the loop (is it the waiting or the issuing that costs?)
+#endif
+#ifndef PROBE_NOFRAG
+#define PROBE_NOFRAG 0 // 1: fragments are read once, before the loop (does the staging compete with the fragment reads for the LDS port?)
+#endif
 #ifndef PROBE_NODMA
 #define PROBE_NODMA 0 // 1: no staging inside the loop (the pace of fragment reads + matrix instructions + barriers)
 #endif
@@ -211,14 +217,17 @@ __global__ __launch_bounds__(512, 1) void i8_loop_kernel(const signed char *A, c
         if (!PROBE_NODMA && grp == 0 && kt + STAGES - 1 < nk)
             DMA(nxt, kt + STAGES - 1)
         const int bo = cur * STAGE;
+        if (!PROBE_NOFRAG || kt == 0)
+        {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-            fb[ni] = LD(bo + fragB + ni * 32 * BKB);
+            for (int ni = 0; ni < 2; ++ni)
+                fb[ni] = LD(bo + fragB + ni * 32 * BKB);
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+            for (int d = 0; d < 3; ++d)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                fa[d][mi] = LD(bo + d * A_PL + fragA + mi * 32 * BKB);
+                for (int mi = 0; mi < 2; ++mi)
+                    fa[d][mi] = LD(bo + d * A_PL + fragA + mi * 32 * BKB);
+        }
         if (!PROBE_LOCKSTEP)
         {
             __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(512, 1) void i8_loop_kernel(const signed char *A, c
                     acc[d][mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[d][mi], fb[ni], acc[d][mi][ni], 0, 0, 0);
         if (!PROBE_LOCKSTEP)
             __builtin_amdgcn_s_setprio(0);
-        if (!PROBE_NODMA && grp == 0 && kt + 1 < nk)
+        if (!PROBE_NODMA && !PROBE_NOWAIT && grp == 0 && kt + 1 < nk)
         {
             // tile kt + 1 has landed; up to STAGES - 2 newer batches stay in flight
             const int newer = min(STAGES - 2, nk - 2 - kt);
