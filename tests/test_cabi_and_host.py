@@ -130,26 +130,64 @@ def test_backend_error_is_propagated(pkg):
     assert e.value.code == 13
 
 
-def test_device_code_has_no_low_half_op_sel_on_packed_fp32(tmp_path):
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """The gfx950 assembly of the engine, compiled once with the Makefile's flags (hipcc cross-compiles without a GPU)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    mk = (ROOT / "umx.cpp_amd" / "Makefile").read_text()
+    assert "-fno-slp-vectorize" in mk
+    out = tmp_path_factory.mktemp("asm") / "engine.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "umx.cpp_amd" / "csrc" / "engine.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out.read_text()
+
+
+def test_device_code_has_no_low_half_op_sel_on_packed_fp32(device_asm):
     """MI355X erratum found in round 1 (tools/pk_mfma_probe.hip): v_pk_add/mul/fma_f32 whose LOW result
     half selects the HIGH half of a source (op_sel bit set) return wrong values while a co-resident wave issues
     v_mfma_f32_32x32x16_bf16 -- which this engine's GEMMs do all the time.  The build therefore uses
     -fno-slp-vectorize and scalar horizontal adds; this test disassembles the device code and fails if a compiler
     or source change reintroduces such a form."""
     import re
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    mk = (ROOT / "umx.cpp_amd" / "Makefile").read_text()
-    assert "-fno-slp-vectorize" in mk
-    out = tmp_path / "engine.s"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
-           f"-I{ROOT / 'include'}", "-S", "--cuda-device-only", "-o", str(out), str(ROOT / "umx.cpp_amd" / "csrc" / "engine.hip")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
     bad = []
-    for line in out.read_text().splitlines():
+    for line in device_asm.splitlines():
         m = re.match(r"\s*(v_pk_(?:add|mul|fma)_f32)\b.*\bop_sel:\[([01,]+)\]", line)
         if m and "1" in m.group(2):
             bad.append(line.strip())
     assert not bad, bad[:5]
+
+
+def test_hot_kernels_keep_their_register_budgets(device_asm):
+    """The kernels a 32-lane step spends its time in are written against a register budget: a source or
+    compiler change that makes one of them spill -- the first persistent form of the fused Wiener kernel spilled 117 registers
+    and nobody would have seen it in a parity test -- must fail here.  Read from the code object's metadata."""
+    import re
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", device_asm):
+        meta[m.group(1)] = (int(m.group(2)), int(m.group(3)))
+
+    def find(*needles):
+        hits = [(k, v) for k, v in meta.items() if all(n in k for n in needles)]
+        assert len(hits) == 1, (needles, [k for k, _ in hits])
+        return hits[0][1]
+
+    # ping-pong plane GEMMs: 8 waves per CU = at most 256 registers; fc1 / W_ih / fc2 main loop + epilogue without a spill
+    # (fc3's epilogue, cold code at the end of a tile, is allowed the handful it has had since round 3)
+    for mode, nbp in ((0, 1), (1, 1), (2, 2)):
+        vg, sp = find(f"gemm_planes_pp_kernelILi{mode}ELi{nbp}E")
+        assert vg <= 256 and sp == 0, (mode, nbp, vg, sp)
+    vg, sp = find("gemm_planes_pp_kernelILi3ELi2E")
+    assert vg <= 256 and sp <= 16, (vg, sp)
+    # batched recurrence, two groups: 12 waves per CU = at most 168
+    vg, sp = find("lstm_batch2_kernelILi512ELi2ELb0E")
+    assert vg <= 168 and sp == 0, (vg, sp)
+    # fused Wiener / inverse STFT / overlap-add: 1024 threads = at most 128
+    vg, sp = find("wiener_istft_kernelILb1ELi4E")
+    assert vg <= 128 and sp == 0, (vg, sp)
+    # single-track recurrence: two grids per CU in the cross-segment pipeline (gemm_common.h: 104 + 136 budget)
+    hits = [v for k, v in meta.items() if "lstm_persistent_kernel" in k]
+    assert hits and all(sp == 0 for _, sp in hits), hits
