@@ -15,6 +15,13 @@ in this container -- they pin the oracle (oracle/umx_oracle.cpp) against restate
   split_f64.npz    numpy float64 restatement of split_inference's chunking, triangular transition weights, weighted
                    overlap-add and normalisation (umx.cpp:181-273, sum_weight zeroed = F4 fixed) and of
                    shift_inference's padding/crop (umx.cpp:115-147) around a known per-segment function
+  quantizer_ref.npz  (round 4) THE REFERENCE'S OWN quantiser: `quantize` / `dequantize` are lifted out of
+                   /root/reference/scripts/convert-umx-pth-to-ggml.py:13-34 by AST at generation time (the script's top-level
+                   `import openunmix` is the only thing that keeps it from being imported here; the two functions are pure
+                   numpy) and RUN on seeded tensors: every tensor of one synthetic target at hidden 16 with the script's own
+                   u8 / u16 rule (:146-150), plus constant, single-element and extreme-range tensors.  Stored: (scale, offset)
+                   and the sha256 of q and of the dequantised fp32 bytes per tensor, the small tensors in full.  No reference
+                   source text is stored -- only what the functions returned.
 Only seeds + expected outputs are stored; inputs are regenerated from the seed by the tests.
 gspi_mono.wav / gspi_stereo.wav are the reference's own test data files (test/data/), copied as data.
 """
@@ -197,10 +204,84 @@ def new_goldens(pkg):
     print("new golden fixtures written")
 
 
+QUANT_HIDDEN, QUANT_SEED = 16, 909
+
+
+def quant_special_cases():
+    """Inputs of the special cases, regenerated by the test from this function (seeded / closed form)."""
+    rng = np.random.default_rng(910)
+    return {
+        "single": np.array([0.37], np.float32),
+        "two_equal_steps": np.array([-1.0, 1.0], np.float32),
+        "constant": np.full(7, 0.25, np.float32),  # scale = 0: 0/0 in the reference quantiser (NaN -> integer cast), whatever it gives
+        "tiny_range": (1.0 + rng.uniform(0, 1e-6, 33)).astype(np.float32),
+        "huge_range": (rng.standard_normal(65) * 1e30).astype(np.float32),
+        "denormal": (rng.uniform(-1, 1, 40) * 1e-41).astype(np.float32),
+        "ties": (np.arange(0, 510, dtype=np.float32) * 0.5),  # x.5 quotients: numpy rounds half to even
+        "negative_only": (-np.abs(rng.standard_normal(50)) - 3).astype(np.float32),
+    }
+
+
+def reference_quantiser():
+    """`quantize`, `dequantize` of the reference's converter, lifted by AST (build container only)."""
+    import ast
+    src = Path("/root/reference/scripts/convert-umx-pth-to-ggml.py").read_text()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("quantize", "dequantize")]
+    assert [f.name for f in fns] == ["quantize", "dequantize"]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "convert-umx-pth-to-ggml.py", "exec"), ns)  # noqa: S102
+    return ns["quantize"], ns["dequantize"]
+
+
+def quant_goldens(pkg):
+    import hashlib
+    import warnings
+    rq, rd = reference_quantiser()
+    W = pkg.ggml.synth_weights(QUANT_HIDDEN, seed=QUANT_SEED)[0]
+    out = {"hidden": QUANT_HIDDEN, "wseed": QUANT_SEED, "numpy": np.__version__}
+    names = pkg.ggml.tensor_names()
+    scales, offsets, qsha, dsha = [], [], [], []
+    for nm in names:
+        data = W[nm].astype(np.float32)
+        # the converter's own rule, convert-umx-pth-to-ggml.py:146-150
+        if any([x in nm for x in ["bn2", "bn3", "fc2", "fc3"]]):
+            q, scale, offset = rq(data, qtype=np.uint16)
+        else:
+            q, scale, offset = rq(data)
+        import struct
+        scale32, offset32 = struct.unpack("ff", struct.pack("ff", scale, offset))  # what :154 writes to the file
+        deq = np.asarray(rd(q, np.float32(scale32), np.float32(offset32)))
+        assert deq.dtype == np.float32, deq.dtype
+        scales.append(scale32)
+        offsets.append(offset32)
+        qsha.append(hashlib.sha256(np.ascontiguousarray(q).tobytes()).hexdigest())
+        dsha.append(hashlib.sha256(np.ascontiguousarray(deq).tobytes()).hexdigest())
+        if data.ndim == 1:
+            out["q/" + nm] = q
+            out["deq/" + nm] = deq
+    out.update(names=np.array(names), scale=np.array(scales, np.float32), offset=np.array(offsets, np.float32),
+               q_sha256=np.array(qsha), deq_sha256=np.array(dsha))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for nm, a in quant_special_cases().items():
+            for qt in (np.uint8, np.uint16):
+                q, scale, offset = rq(a, qtype=qt)
+                key = f"special/{nm}/{np.dtype(qt).name}"
+                out[key + "/q"] = q
+                out[key + "/scale"] = np.float32(scale)
+                out[key + "/offset"] = np.float32(offset)
+                out[key + "/deq"] = np.asarray(rd(q, np.float32(scale), np.float32(offset)), np.float32)
+    np.savez_compressed(HERE / "quantizer_ref.npz", **out)
+    print("quantizer_ref.npz written:", len(names), "tensors +", len(quant_special_cases()) * 2, "special cases")
+
+
 def main():
     pkg = ge.load_package()
     if len(sys.argv) > 1 and sys.argv[1] == "new":  # only the fixtures added in round 2
         return new_goldens(pkg)
+    if len(sys.argv) > 1 and sys.argv[1] == "quant":  # round 4: the reference's own quantiser, run here
+        return quant_goldens(pkg)
     # ---- 1. float64 STFT / iSTFT
     rng = np.random.default_rng(101)
     n, n_buf = 6000, 8192

@@ -93,3 +93,66 @@ def test_plain_and_gzip_files_load_identically(pkg, model_small, tmp_path):
     p.write_bytes(_raw(path))
     a, b = pkg.HostModel(path), pkg.HostModel(p)
     assert (a.dequantize(2, "fc2.weight") == b.dequantize(2, "fc2.weight")).all()
+
+
+# ---- the reference's OWN quantiser (convert-umx-pth-to-ggml.py:13-34), run in the build container by
+# tests/golden/make_golden.py quant: the first reference-generated fixture behind the STFT
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def quant_ref():
+    from pathlib import Path
+    return np.load(Path(__file__).parent / "golden" / "quantizer_ref.npz")
+
+
+def test_quantiser_reproduces_the_reference_quantiser_bit_for_bit(pkg, quant_ref):
+    g = quant_ref
+    W = pkg.ggml.synth_weights(int(g["hidden"]), seed=int(g["wseed"]))[0]
+    names = [str(n) for n in g["names"]]
+    assert names == pkg.ggml.tensor_names()
+    for i, nm in enumerate(names):
+        q, scale, offset = pkg.ggml.quantize(W[nm], np.uint16 if pkg.ggml.is_u16(nm) else np.uint8)
+        assert q.dtype == (np.uint16 if pkg.ggml.is_u16(nm) else np.uint8), nm  # the converter's rule, :146-150
+        assert np.float32(scale).tobytes() == g["scale"][i].tobytes() and np.float32(offset).tobytes() == g["offset"][i].tobytes(), nm
+        assert _sha(q) == str(g["q_sha256"][i]), nm
+        deq = pkg.ggml.dequantize(q, scale, offset)
+        assert deq.dtype == np.float32 and _sha(deq) == str(g["deq_sha256"][i]), nm
+        if W[nm].ndim == 1:  # small tensors are stored in full
+            assert (q == g["q/" + nm]).all() and (deq == g["deq/" + nm]).all(), nm
+
+
+def test_quantiser_special_cases_match_the_reference_quantiser(pkg, quant_ref):
+    import importlib.util
+    import warnings
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("make_golden", Path(__file__).parent / "golden" / "make_golden.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # constant tensors divide 0 by 0 in the reference, too
+        for nm, a in mg.quant_special_cases().items():
+            for qt in (np.uint8, np.uint16):
+                key = f"special/{nm}/{np.dtype(qt).name}"
+                q, scale, offset = pkg.ggml.quantize(a, qt)
+                assert (q == quant_ref[key + "/q"]).all(), key
+                assert np.float32(scale).tobytes() == quant_ref[key + "/scale"].tobytes(), key  # bits: NaN-safe
+                assert np.float32(offset).tobytes() == quant_ref[key + "/offset"].tobytes(), key
+                assert pkg.ggml.dequantize(q, scale, offset).tobytes() == quant_ref[key + "/deq"].tobytes(), key
+
+
+def test_loaders_dequantise_a_reference_quantised_file_bit_for_bit(pkg, po, quant_ref, tmp_path):
+    """A model file whose first target holds the fixture's tensors: host/model.cpp's loader and the oracle's loader
+    (model.cpp:578-665 restated twice) return exactly what the reference's `dequantize` returned for them."""
+    g = quant_ref
+    H = int(g["hidden"])
+    path = str(tmp_path / "quantref.bin.gz")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=int(g["wseed"])), H)
+    hm, om = pkg.HostModel(path), po.Model.load(path)
+    _, targets = pkg.ggml.read_model(path)
+    for i, nm in enumerate(pkg.ggml.tensor_names()):
+        assert _sha(targets[0][nm]["q"]) == str(g["q_sha256"][i]), nm  # the bytes in the file are the reference's q
+        assert _sha(hm.dequantize(0, nm)) == str(g["deq_sha256"][i]), nm
+        assert _sha(np.asarray(om.tensor(0, i), np.float32)) == str(g["deq_sha256"][i]), nm

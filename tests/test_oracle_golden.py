@@ -185,3 +185,18 @@ def test_segment_drivers_vs_float64_numpy(pkg, po):
     for t in range(4):
         assert np.abs(got[t] - ref[t]).max() < 2e-6, t
     assert np.abs(sw[::ev] - g["sum_weight"]).max() < 1e-6
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """`make -C oracle sanitize`: the restatement's entry points on a short segment / ragged track under ASan + UBSan
+    (the reference has no sanitizer target either; the checker should not be the thing with the stray read)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no compiler")
+    p = subprocess.run(["make", "-C", str(Path(__file__).resolve().parent.parent / "oracle"), "sanitize"],
+                       capture_output=True, text=True, timeout=600)
+    if "cannot find -lasan" in p.stderr or "cannot find -lubsan" in p.stderr:
+        pytest.skip("sanitizer runtimes not installed")
+    assert p.returncode == 0 and "selftest: ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

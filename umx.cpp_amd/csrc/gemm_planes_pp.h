@@ -138,6 +138,11 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
 
+// timing builds only (garbage results), tools/build_variants.sh: 1 = no staging inside the main loop, 2 = no matrix
+// instructions, 4 = no fragment reads, 8 = no epilogue (stores of row 0 only) -- which side sets the pace of the shipped loop
+#ifndef PP_EXPERIMENT
+#define PP_EXPERIMENT 0
+#endif
     const int nk = K / GP_BK;
     if (grp == 0)
     {
@@ -161,14 +166,16 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         for (int ph = 0; ph < PH; ++ph)
         {
             // M: the stage of tile kt - 1 was last read by group 1 one phase ago
-            if (ph == 0 && grp == 0 && kt + STAGES - 1 < nk)
+            if (!(PP_EXPERIMENT & 1) && ph == 0 && grp == 0 && kt + STAGES - 1 < nk)
                 PP_DMA(nxt, (kt + STAGES - 1) * GP_BK)
-            PP_LOAD(cur, ph)
+            if (!(PP_EXPERIMENT & 4) || kt == 0)
+                PP_LOAD(cur, ph)
             PP_WAIT_LDS();
             PP_BARRIER()
             // C
             __builtin_amdgcn_s_setprio(1);
-            PP_MMA()
+            if (!(PP_EXPERIMENT & 2) || kt == 0)
+                PP_MMA()
             __builtin_amdgcn_s_setprio(0);
             if (ph == PH - 1 && grp == 0 && kt + 1 < nk)
             {
@@ -235,6 +242,18 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
     ea.Tp_lane = args.Tp_lane;
     ea.lanes = args.lanes;
     ea.mag_lane = args.mag_lane;
+    if (PP_EXPERIMENT & 8)
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                s += acc[mi][0][r] + acc[mi][1][r];
+        if (s == 12345.678f)
+            tg.C[tid] = s;
+        return;
+    }
 #pragma unroll
     for (int half = 0; half < MI / 2; ++half)
         gemm_epilogue<MODE>(et, ea, m0 + wm * 32 * MI + half * 64, n0, 0, wn, lr, lh, acc[2 * half][0], acc[2 * half][1], acc[2 * half + 1][0],
