@@ -40,6 +40,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 import tempfile
 import time
@@ -350,15 +351,23 @@ def main():
         value = world * B * args.steps * seg_sec / dt
         gemm, rec, byt = algorithmic_work(T, H)
         flavour = args.gemm or os.environ.get("UMX_GEMM") or ("planes" if batched else "bf16x3")
-        traffic_src = args.traffic_csv or next(iter(sorted(glob.glob(str(ROOT / "profiles" / "r*_pmc_fetch_write_per_kernel.csv")),
-                                                           reverse=True)), None)
+        def pmc_order(path):
+            # profiles/r<round>_v<version>_pmc_fetch_write_per_kernel.csv: newest = largest (round, version) as NUMBERS
+            # (a string sort puts r03_v9 behind r03_v10)
+            mm = re.match(r"r(\d+)_v(\d+)_", os.path.basename(path))
+            return (int(mm.group(1)), int(mm.group(2))) if mm else (-1, -1)
+        traffic_src = args.traffic_csv or max(glob.glob(str(ROOT / "profiles" / "r*_pmc_fetch_write_per_kernel.csv")), key=pmc_order, default=None)
         traffic = read_traffic(traffic_src) if traffic_src else {}
+        traffic_missing = []
 
         def find_traffic(*needles):
-            # a needle may be a tuple of alternatives (the u8 GEMMs run as gemm_planes_pp_kernel, older CSVs hold gemm_planes_kernel)
+            # the counter row of THIS kernel or nothing: no fall-back to another kernel's row (a needle that is not in the
+            # summary is reported in roofline.traffic_missing, and the entry's traffic is null)
             for kk, v in traffic.items():
-                if all(any(a in kk for a in (nd if isinstance(nd, tuple) else (nd,))) for nd in needles):
+                if all(nd in kk for nd in needles):
                     return v
+            if traffic:
+                traffic_missing.append(" ".join(needles))
             return None
 
         # ---- one entry per kernel family: launches per step, live duration per launch, work per launch, roof
@@ -391,10 +400,10 @@ def main():
         # 256 x 256 launches run the ping-pong form of the plane GEMM (csrc/gemm_planes_pp.h), unless UMX_GEMM_PP says otherwise
         pp = flavour == "planes" and os.environ.get("UMX_GEMM_PP") is None and B * T >= 4096
         g8 = "gemm_planes_pp_kernel" if pp else gname
-        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{g8}<G_FC1>", ((g8 + "<0,", gname + "<0,"),)),
-                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{g8}<G_IH>", ((g8 + "<1,", gname + "<1,"),)),
-                   gemm_entry(["fc2"], "fc2", p16, f"{g8}<G_FC2>", ((g8 + "<2,", gname + "<2,"),)),
-                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{g8}<G_FC3>", ((g8 + "<3,", gname + "<3,"),))]
+        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{g8}<G_FC1>", (g8 + "<0,",)),
+                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{g8}<G_IH>", (g8 + "<1,",)),
+                   gemm_entry(["fc2"], "fc2", p16, f"{g8}<G_FC2>", (g8 + "<2,",)),
+                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{g8}<G_FC3>", (g8 + "<3,",))]
         lstm_keys = [f"lstm_rec{l}" for l in range(3)]
         lms = sum(stage_ms.get(kk, 0.0) for kk in lstm_keys) / 3
         lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3
@@ -466,6 +475,7 @@ def main():
             roofline["bound_note"] = ("neither hbm nor mfma binds this kernel: 3*T serially dependent steps, each a chain-wide hand-off "
                                       "(SURVEY 8d); `peak` is the peak of the pipe it issues on, `frac` what the algorithmic flops make of it")
         roofline["traffic_source"] = os.path.relpath(traffic_src, ROOT) if traffic_src and traffic else None
+        roofline["traffic_missing"] = traffic_missing or None  # kernels of this run with no row in that summary
         roofline["share_of_device_time"] = round(dominant["launch_ms"] * dominant["launches_per_step"] /
                                                  max(sum(kk["launch_ms"] * kk["launches_per_step"] for kk in kernels), 1e-9), 3)
         gemm_alone_ms = sum(kk["launch_ms_alone"] * kk["launches_per_step"] for kk in kernels[:4])

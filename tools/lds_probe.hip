@@ -5,6 +5,10 @@
 //   mode 0  all eight waves read (no DMA)            mode 1  four waves (one per SIMD) read
 //   mode 2  group 1 reads, group 0 issues the DMA    mode 3  DMA alone (group 0)
 //   mode 4  all eight waves read, group 0 also issues the DMA
+//   mode 5  DMA alone, dealt to all eight waves (6 pieces each)
+//   mode 6  DMA alone (group 0), pieces of 8 rows x 128 B (whole lines) instead of 16 rows x 64 B
+//   mode 7  DMA alone (group 0), pieces of 1 KiB contiguous (K-tiled planes)
+//   mode 8  DMA alone, whole-line pieces dealt to all eight waves
 // Output: bytes per shader clock and CU (clock64 = s_memtime ticks = shader cycles), and TB/s over the chip from the wall time.
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/lds_probe tools/lds_probe.hip ; run: tools/lds_probe
 #include <hip/hip_runtime.h>
@@ -26,10 +30,11 @@ template <int MODE> __global__ __launch_bounds__(512, 1) void probe(const unsign
     const int sw = (lr >> 2) & 3;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
     const bool reads = MODE == 0 || MODE == 4 || (MODE == 1 && grp == 0) || (MODE == 2 && grp == 1);
-    const bool dma = (MODE == 2 || MODE == 3 || MODE == 4) && grp == 0;
+    const bool dma = ((MODE == 2 || MODE == 3 || MODE == 4 || MODE == 6 || MODE == 7) && grp == 0) || MODE == 5 || MODE == 8;
+    constexpr int DEAL = (MODE == 5 || MODE == 8) ? 8 : 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(src), 0, 0x7fffffff, 0x00020000);
     const int st_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-    const int voff = ((lane >> 2) * row_elems) * 2 + st_chunk * 16;
+    const int voff = (MODE == 6 || MODE == 8) ? ((lane >> 3) * row_elems) * 2 + (lane & 7) * 16 : MODE == 7 ? lane * 16 : ((lane >> 2) * row_elems) * 2 + st_chunk * 16;
     const long band = (long)blockIdx.x * 256 * row_elems * 2; // this workgroup's 256 rows (re-read from the L2 / MALL)
     // fragment addresses of PP_LOAD: wave tile 128 x 64 at (wm = grp, wn = ws)
     const unsigned fragA = lds0 + (grp * 128 + lr) * 64, fragB = lds0 + 2 * A_PL + (ws * 64 + lr) * 64;
@@ -43,13 +48,16 @@ template <int MODE> __global__ __launch_bounds__(512, 1) void probe(const unsign
         {
             const int k0 = (t * 32) % row_elems;
 #pragma unroll
-            for (int i0 = 0; i0 < 48; i0 += 4) // 32 A groups (two planes: here two column halves) + 16 B groups of 1 KiB
+            for (int i0 = 0; i0 < 48; i0 += DEAL) // 32 A groups (two planes: here two column halves) + 16 B groups of 1 KiB
             {
-                const int i = i0 + ws;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(size_t)(lds0 + cur * BUF + i * 1024), 16, voff,
-                                                         (int)(band + ((long)(16 * (i & 15)) * row_elems + k0 + (i >> 4) * 32) * 2), 0, 0);
+                const int i = i0 + (DEAL == 8 ? wave : ws);
+                const long src_off = (MODE == 6 || MODE == 8) ? ((long)(8 * (i & 31)) * row_elems + ((t * 64) % row_elems) + (i >> 5) * 64) * 2
+                                     : MODE == 7            ? ((long)(t % 10) * 48 + i) * 1024
+                                                            : ((long)(16 * (i & 15)) * row_elems + k0 + (i >> 4) * 32) * 2;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(size_t)(lds0 + cur * BUF + i * 1024), 16, voff, (int)(band + src_off), 0, 0);
             }
-            __builtin_amdgcn_s_waitcnt(0x0f70 | (24 & 15) | ((24 >> 4) << 14)); // two trips in flight, as the kernel
+            constexpr int INFL = 2 * 48 / DEAL; // two trips in flight, as the kernel
+            __builtin_amdgcn_s_waitcnt(0x0f70 | (INFL & 15) | ((INFL >> 4) << 14));
         }
         if (reads)
         {
@@ -98,7 +106,7 @@ template <int MODE> static void run(const char *what, const unsigned short *src,
     hipMemcpy(c.data(), d_cyc, blocks * 8, hipMemcpyDeviceToHost);
     std::sort(c.begin(), c.end());
     const double med = (double)c[blocks / 2];
-    const int readers = MODE == 0 || MODE == 4 ? 8 : (MODE == 3 ? 0 : 4);
+    const int readers = MODE == 0 || MODE == 4 ? 8 : ((MODE == 3 || MODE >= 5) ? 0 : 4);
     const bool dma = MODE >= 2;
     const double rd_bytes = (double)readers * 20 * 1024 * trips, wr_bytes = dma ? 48.0 * 1024 * trips : 0.0;
     printf("%-52s %8.3f ms  clock %.2f GHz  cycles/trip %7.1f  reads %6.1f B/clk/CU  dma writes %5.1f B/clk/CU  total %6.1f B/clk/CU  "
@@ -124,5 +132,9 @@ int main()
     run<3>("mode 3: LDS-DMA alone (group 0, 48 KB per trip)", src, row_elems, trips, d_cyc, d_sink);
     run<2>("mode 2: group 1 reads beside group 0's LDS-DMA", src, row_elems, trips, d_cyc, d_sink);
     run<4>("mode 4: eight waves read, group 0 also issues the DMA", src, row_elems, trips, d_cyc, d_sink);
+    run<5>("mode 5: LDS-DMA alone, dealt to all eight waves", src, row_elems, trips, d_cyc, d_sink);
+    run<6>("mode 6: LDS-DMA alone (group 0), 8 rows x 128 B pieces", src, row_elems, trips, d_cyc, d_sink);
+    run<7>("mode 7: LDS-DMA alone (group 0), 1 KiB contiguous pieces", src, row_elems, trips, d_cyc, d_sink);
+    run<8>("mode 8: LDS-DMA alone, 8 rows x 128 B pieces, all eight waves", src, row_elems, trips, d_cyc, d_sink);
     return 0;
 }

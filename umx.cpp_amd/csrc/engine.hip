@@ -10,6 +10,7 @@
 // for the multi-GPU state-carry mode, weight residency (u8/u16 as stored, or expanded) and the GEMM flavour.
 #include "../../include/umx_hip.h"
 #include <chrono>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -112,6 +113,49 @@ enum
 enum { SP_XS = 0, SP_CATL, SP_LA, SP_LB, SP_CATR, SP_A2 }; // which A operand launch_split prepares
 const char *kStageNames[ST_COUNT] = {"stft",  "fc1", "lstm_ih0", "lstm_rec0", "lstm_ih1", "lstm_rec1", "lstm_ih2",
                                      "lstm_rec2", "fc2", "fc3_mask", "wiener",  "istft",    "ola"};
+
+// roctx ranges per stage (tracing): every stage marker below also opens a named range on the calling thread
+// ("umx:<stage>": the HOST span in which the stage's kernels are queued; rocprofv3 --marker-trace shows them beside the
+// kernel trace).  The marker library is looked up at run time (rocprofiler-sdk's, then roctracer's): no link dependency,
+// and without a profiler attached the calls are a null-pointer test.
+namespace
+{
+struct RoctxApi
+{
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi()
+    {
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"})
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))
+            {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop)
+                    return;
+                push = nullptr;
+                pop = nullptr;
+            }
+    }
+};
+thread_local bool t_stage_range_open = false;
+// closes the calling thread's open stage range and opens `stage` (< 0: only closes)
+inline void stage_range(int stage)
+{
+    static const RoctxApi api;
+    if (!api.push)
+        return;
+    if (t_stage_range_open)
+        api.pop();
+    t_stage_range_open = stage >= 0 && stage < ST_COUNT;
+    if (t_stage_range_open)
+    {
+        char name[40];
+        snprintf(name, sizeof name, "umx:%s", kStageNames[stage]);
+        api.push(name);
+    }
+}
+} // namespace
 
 // One track lane of a pipeline slot = the activations of one in-flight segment of one track.
 struct Lane
@@ -1797,6 +1841,7 @@ void umx_hip_ctx::launch_gemm_lanes(Slot &sl, hipStream_t st, int nb, const floa
 int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, const int *n, const int *active,
                              int nact)
 {
+    stage_range(ST_STFT);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_STFT], st));
     {
         StftIn in;
@@ -1811,8 +1856,10 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
         hipLaunchKernelGGL(stft_kernel, dim3(T, in.lanes.count), dim3(256), 0, st, in, N, T, window, tw1, tw2, L0.spec, lane_strides().spec, L0.x,
                            (size_t)Tp * KX, L0.maxabs);
     }
+    stage_range(ST_FC1);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC1], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC1, 0, active, nact, false);
+    stage_range(ST_IH0);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_IH, 0, active, nact, false);
     return UMX_OK;
@@ -1830,8 +1877,10 @@ int umx_hip_ctx::stage_back(Slot &sl, hipStream_t st, int nb, const float *const
 int umx_hip_ctx::stage_masks(Slot &sl, hipStream_t st, int nb, const float *const *audio_dev, unsigned flags, const int *active, int nact)
 {
     const bool dbg = flags & UMX_FLAG_DEBUG_TAPS;
+    stage_range(ST_FC2);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC2], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC2, 0, active, nact, dbg);
+    stage_range(ST_FC3);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_FC3], st));
     launch_gemm_lanes(sl, st, nb, audio_dev, G_FC3, 0, active, nact, dbg);
     UMX_HIP_CHECK(hipGetLastError());
@@ -1848,6 +1897,7 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
                 for (int tg = 0; tg < 4; ++tg) // a skipped target contributes an all-zero magnitude
                     if (flags & UMX_FLAG_SKIP_TARGET(tg))
                         UMX_HIP_CHECK(hipMemsetAsync(sl.lane[ln].ta[tg].mag, 0, sizeof(float) * 2 * T * MAGP, st));
+    stage_range(ST_WIENER);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_WIENER], st));
     const int bt = (NBINS + 255) / 256;
     const LaneSet lanes = lane_set(nb, audio_dev);
@@ -1902,6 +1952,7 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
         oo.n[i] = n[ln];
         nmax = std::max(nmax, n[ln]);
     }
+    stage_range(ST_ISTFT);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_ISTFT], st));
     if (!wiener_fused)
     {
@@ -1930,16 +1981,19 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
         else if (nsrc == 2) { if (nowi) UMX_WI(false, 2); else UMX_WI(true, 2); }
         else { if (nowi) UMX_WI(false, 4); else UMX_WI(true, 4); }
 #undef UMX_WI
+        stage_range(ST_OLA);
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
         hipLaunchKernelGGL(wiener_ola_edges_kernel, dim3(3 * HOP / 256, nruns * 4, lanes.count), dim3(256), 0, st, L0.frames, ls.frames, T, run_len, oo);
     }
     if (!wiener_fused)
     {
+        stage_range(ST_OLA);
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
         if (sl.out_free_valid) // the stems this slot wrote two calls ago are still being downloaded from the same buffers
             UMX_HIP_CHECK(hipStreamWaitEvent(st, sl.out_free, 0));
         hipLaunchKernelGGL(istft_ola_kernel, dim3((nmax + 255) / 256, 4, lanes.count), dim3(256), 0, st, L0.frames, ls.frames, T, oo);
     }
+    stage_range(-1);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_COUNT], st));
     UMX_HIP_CHECK(hipGetLastError());
     sl.have_times = true;
@@ -2040,11 +2094,13 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
     {
         if (layer > 0)
         {
+            stage_range(ST_IH0 + 2 * layer);
             UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
             launch_gemm_lanes(sl, st, nb, audio_dev, G_IH, layer, active, nact, false);
         }
         if (prev.used) // the previous segment's layer `layer` must have left its final h/c (F3)
             UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.rec_done[two_grids ? layer : 2], 0));
+        stage_range(ST_LSTM0 + 2 * layer);
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
         if (call_idx < (size_t)kBackupCalls) // the state this layer starts from (the previous segment's layer has finished)
             UMX_HIP_CHECK(hipMemcpyAsync(backup + (call_idx * 3 + layer) * state_floats() * B, state, sizeof(float) * state_floats() * B,
@@ -2425,12 +2481,14 @@ int umx_hip_ctx::phase_layer(int layer)
     active_list(ph_flags, active, nact);
     if (layer > 0)
     {
+        stage_range(ST_IH0 + 2 * layer);
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_IH0 + 2 * layer], st));
         {
             const float *ain = ph_audio ? ph_audio : audio_in;
             launch_gemm_lanes(sl, st, 1, &ain, G_IH, layer, active, nact, false);
         }
     }
+    stage_range(ST_LSTM0 + 2 * layer);
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_LSTM0 + 2 * layer], st));
     if (nact > 0)
         if (int rc = run_lstm_layer(sl, layer, active, nact, ph_flags & UMX_FLAG_LSTM_STEPWISE, 1u))

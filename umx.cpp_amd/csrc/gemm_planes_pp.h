@@ -21,6 +21,10 @@
 #pragma once
 #include "gemm_planes.h"
 
+#ifndef PP_DMA_BOTH
+#define PP_DMA_BOTH 1 // 0: group 0 issues every piece of the staging (the form of round 3; A/B builds)
+#endif
+
 namespace umx
 {
 
@@ -61,19 +65,27 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
     const int voffA = ((lane >> 2) * lda) * 2 + st_chunk * 16, voffB = ((lane >> 2) * K) * 2 + st_chunk * 16;
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr)gp_smem;
     const long a_plane_b = (long)args.a_plane * 2, b_plane_b = (long)args.N * K * 2;
-    constexpr int A_GROUPS = 2 * (BM / 16), B_GROUPS = NBP * (BN / 16), DMA_PER_WAVE = (A_GROUPS + B_GROUPS) / 4;
-    static_assert(DMA_PER_WAVE <= 16, "vmcnt bookkeeping below");
+    // BOTH (three stages = one-plane weights): each group issues HALF of a tile's pieces, in its own M phase.  With all of
+    // them in group 0's M phase the L2 -> LDS path (31 B/clk/CU with every CU streaming, tools/lds_probe mode 3: 48 KB need
+    // ~1,570 cycles) has one 1,024-cycle phase to take a whole tile and none in the next: the phase stretches to the path's
+    // pace and the partner's matrix instructions wait at the barrier (profiles/r04_pp_pace_experiments.txt: W_ih 4.9 ms with
+    // the staging, 3.6 without).  Dealt to both phases the path is busy all the time at 24 KB per phase.
+    constexpr bool BOTH = PP_DMA_BOTH && STAGES == 3;
+    constexpr int DEAL = BOTH ? 8 : 4; // pieces i = it DEAL + deal0 + SIMD: dealt to the eight waves, or to group 0's four
+    constexpr int A_GROUPS = 2 * (BM / 16), B_GROUPS = NBP * (BN / 16), DMA_PER_WAVE = (A_GROUPS + B_GROUPS) / DEAL;
+    static_assert(DMA_PER_WAVE <= 16 && A_GROUPS % DEAL == 0 && B_GROUPS % DEAL == 0, "vmcnt bookkeeping below");
+    const int deal0 = BOTH ? 4 * grp : 0;
 #define PP_DMA(buf, k0)                                                                                              \
     {                                                                                                                \
-        _Pragma("unroll") for (int i0 = 0; i0 < A_GROUPS; i0 += 4)                                                   \
+        _Pragma("unroll") for (int it = 0; it < A_GROUPS / DEAL; ++it)                                               \
         {                                                                                                            \
-            const int i = i0 + ws, p = i / (BM / 16), j = i % (BM / 16);                                             \
+            const int i = it * DEAL + deal0 + ws, p = i / (BM / 16), j = i % (BM / 16);                              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(size_t)(lds0 + (buf)*BUF_BYTES + p * A_PL + j * 1024), 16, voffA, \
                                                      (int)(p * a_plane_b + ((long)(m0 + 16 * j) * lda + (k0)) * 2), 0, 0); \
         }                                                                                                            \
-        _Pragma("unroll") for (int i0 = 0; i0 < B_GROUPS; i0 += 4)                                                   \
+        _Pragma("unroll") for (int it = 0; it < B_GROUPS / DEAL; ++it)                                               \
         {                                                                                                            \
-            const int i = i0 + ws, p = i / (BN / 16), j = i % (BN / 16);                                             \
+            const int i = it * DEAL + deal0 + ws, p = i / (BN / 16), j = i % (BN / 16);                              \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(size_t)(lds0 + (buf)*BUF_BYTES + 2 * A_PL + p * B_PL + j * 1024), 16, voffB, \
                                                      (int)(p * b_plane_b + ((long)(n0 + 16 * j) * K + (k0)) * 2), 0, 0); \
         }                                                                                                            \
@@ -144,7 +156,7 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
 #define PP_EXPERIMENT 0
 #endif
     const int nk = K / GP_BK;
-    if (grp == 0)
+    if (grp == 0 || BOTH)
     {
         PP_DMA(0, 0)
         if (STAGES == 3 && nk > 1)
@@ -166,11 +178,20 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         for (int ph = 0; ph < PH; ++ph)
         {
             // M: the stage of tile kt - 1 was last read by group 1 one phase ago
-            if (!(PP_EXPERIMENT & 1) && ph == 0 && grp == 0 && kt + STAGES - 1 < nk)
+            if (!(PP_EXPERIMENT & 1) && ph == 0 && (grp == 0 || BOTH) && kt + STAGES - 1 < nk)
                 PP_DMA(nxt, (kt + STAGES - 1) * GP_BK)
             if (!(PP_EXPERIMENT & 4) || kt == 0)
                 PP_LOAD(cur, ph)
             PP_WAIT_LDS();
+            if (BOTH && grp == 1 && kt + 1 < nk)
+            {
+                // group 1's half of tile kt + 1 (issued one trip ago; group 0 reads the tile from the next phase on) has landed;
+                // the pieces of tile kt + 2 it has just issued may stay in flight
+                if (kt + 2 < nk)
+                    PP_WAIT_VM(DMA_PER_WAVE);
+                else
+                    PP_WAIT_VM(0);
+            }
             PP_BARRIER()
             // C
             __builtin_amdgcn_s_setprio(1);

@@ -81,6 +81,12 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
     float2 *const stem = reinterpret_cast<float2 *>(out.p[blockIdx.z][src0 + g]);
     const int n_out = out.n[blockIdx.z];
     [[maybe_unused]] long long pf[5] = {0, 0, 0, 0, 0};
+    float2 open[3][4]; // the open hop blocks' sums at this thread's positions (see the overlap-add below)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            open[c][q] = make_float2(0.f, 0.f);
     for (int f = f0; f < f1; ++f)
     {
     [[maybe_unused]] long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
@@ -170,29 +176,17 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         c3 = clock64();
     // ---- the frame's weighted samples: overlap-added on the way out.  Hop block h = samples [h HOP, (h + 1) HOP) of the
     // padded signal is the sum of chunk h - f of the frames f = h - 3 .. h, in ascending f (dsp.cpp:237-257).  A workgroup
-    // takes its frames in that order, and a position is always the same thread's, so it adds straight into the stem
-    // (crop of dsp.cpp:203-205: sample p - 2048): chunk 3 is a block's first term and is written, chunks 0-2 are added to
-    // what the previous frames left (read past the L1: the line was written since it was last read).  Only the run's first
-    // three blocks also belong to the PREVIOUS run's last frames, whose terms come first: chunks that fall on them are kept
-    // in `frames` and added afterwards, in order, by wiener_ola_edges_kernel.  The 339 MB of frames per 60 s segment that the
-    // separate overlap-add kernel read back (and this kernel wrote) stay in the L2 / MALL as read-modify-writes of the stem.
+    // takes its frames in that order and a position is always the same thread's, so the three OPEN blocks (those that later
+    // frames of the run still add to) ride in registers -- open[c][q] = the sum so far of block f + 1 + c at this thread's
+    // position q of it -- and every stem sample is stored ONCE, when chunk 0 of the block's last frame has been added (crop of
+    // dsp.cpp:203-205: sample p - 2048).  (Round 3 added straight into the stem: 12 device-scope loads and 16 stores per
+    // thread and frame, 27.5 GB of memory-side traffic per 32-lane launch against 10.8 GB algorithmic.)  Chunk 3 is a block's
+    // first term (0 + c, like the separate kernel).  Only the run's first three blocks also belong to the PREVIOUS run's last
+    // frames, whose terms come first: the run's first three frames are kept in `frames` and wiener_ola_edges_kernel adds their
+    // chunks to those blocks afterwards, in order, on top of what the previous run flushed at its end (below the loop).
     float2 *dst = frames + ((size_t)(src0 + g) * T + f) * NFFT;
     const size_t start = (size_t)f * HOP;
     const bool keep = f - f0 < 3; // one of the run's first three frames
-    float2 prev[12];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's stores of the previous frame (same addresses) are in the L2
-#pragma unroll
-    for (int r = 0; r < 12; ++r) // chunks 0-2: what the earlier frames of this run left there
-    {
-        const int i = j + 256 * r, h = f + (r >> 2), s_out = (int)start + i - NFFT / 2;
-        prev[r] = make_float2(0.f, 0.f);
-        if (h >= f0 + 3 && s_out >= 0 && s_out < n_out)
-        {
-            // device-scope load: from the L2, where this thread's store of the previous frame went
-            const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(stem + s_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            prev[r] = make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-        }
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r)
     {
@@ -206,18 +200,23 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         // 7 instead of 22 instructions per sample in a kernel that is bound by its VALU instructions (WI_PROFILE)
         const float rden = __builtin_amdgcn_rcpf(den);
         const float2 val = make_float2(div_by(z.x * w * 1.0f / float(NFFT), den, rden), div_by(z.y * w * 1.0f / float(NFFT), den, rden));
-        const int h = f + (r >> 2), s_out = (int)start + i - NFFT / 2;
         if (keep)
             dst[i] = val;
-        if (h >= f0 + 3 && s_out >= 0 && s_out < n_out)
+        const int c = r >> 2, q = r & 3;
+        const float2 a = c < 3 ? open[c < 3 ? c : 0][q] : make_float2(0.f, 0.f);
+        const float2 sum = make_float2(a.x + val.x, a.y + val.y);
+        if (c == 0)
         {
-            const float2 a = r < 12 ? prev[r < 12 ? r : 0] : make_float2(0.f, 0.f); // chunk 3: the block's first term (0 + c)
-            stem[s_out] = make_float2(a.x + val.x, a.y + val.y);
+            // block f is complete
+            const int s_out = (int)start + i - NFFT / 2;
+            if (f >= f0 + 3 && s_out >= 0 && s_out < n_out)
+                stem[s_out] = sum;
         }
+        else
+            open[c - 1][q] = sum; // block f + c = block (f + 1) + (c - 1)
     }
     // the transforms' buffers are free for the next frame's gains: an LDS-only barrier -- __syncthreads() would also wait for the
-    // acknowledgements of this frame's stores (vmcnt(0)) with every wave idle; the next frame waits for them where it reads the
-    // stem again, two phases later, when they have long arrived
+    // acknowledgements of this frame's stores (vmcnt(0)) with every wave idle, and nothing reads them back
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (WI_PROFILE)
     {
@@ -227,6 +226,20 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         pf[2] += c3 - c2;
         pf[3] += c4 - c3;
     }
+    }
+    // the run's end: blocks f1 .. f1 + 2 hold the terms of this run's last frames; the next run's first frames follow
+    // (wiener_ola_edges_kernel), or nothing does (the end of the segment)
+    {
+        const int j = tid & 255;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+            {
+                const int h = f1 + c, s_out = h * HOP + j + 256 * q - NFFT / 2;
+                if (h >= f0 + 3 && s_out >= 0 && s_out < n_out)
+                    stem[s_out] = open[c][q];
+            }
     }
     if (WI_PROFILE && blockIdx.x == 7 && blockIdx.z == 3 && (tid == 0 || tid == 777))
         printf("# wiener_istft thread %d, %d frames: cycles per frame  loads+gains %lld  barrier %lld  transform %lld  weight+overlap-add+drain %lld\n", tid,
