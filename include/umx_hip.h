@@ -125,9 +125,8 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                           const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
 int umx_hip_n_tracks(const umx_hip_ctx *ctx);
-/* Segments the context keeps in flight (= its pipeline slots, each with its own stream): 2 (3 with UMX_SLOTS=3 in the
- * environment: an experiment, see csrc/engine.hip).  The buffers of that many CONSECUTIVE asynchronous calls must be distinct (ordering contract
- * of umx_hip_infer_segment_device below). */
+/* Segments the context keeps in flight (= its pipeline slots, each with its own stream): 2.  The buffers of that many
+ * CONSECUTIVE asynchronous calls must be distinct (ordering contract of umx_hip_infer_segment_device below). */
 int umx_hip_pipeline_depth(const umx_hip_ctx *ctx);
 int umx_hip_lstm_is_batched(const umx_hip_ctx *ctx);
 size_t umx_hip_weight_bytes(const umx_hip_ctx *ctx); /* HBM bytes held by the model's weight matrices */

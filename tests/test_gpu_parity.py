@@ -619,36 +619,3 @@ def test_cli_end_to_end(pkg, po, tmp_path):
         assert sdr_db(ref[t], got) > MIN_SDR
     bad = subprocess.run([str(cli), path], capture_output=True, text=True)
     assert bad.returncode == 1 and "Usage" in bad.stderr  # umx.cpp:28-33
-
-
-def test_three_pipeline_slots_give_the_bits_of_two(pkg, model_small, monkeypatch):
-    """UMX_SLOTS=3 (an experiment kept in csrc/engine.hip: a third segment in flight; slower) goes through the same
-    slot machinery as the default two -- round-robin streams, per-layer state hand-off from the previous slot, the per-stream
-    admission gate, staging buffers per slot.  Same bits as two slots and as one segment at a time, device and host forms."""
-    import torch
-    torch.zeros(1).cuda()
-    path, om, targets = model_small
-    N, NSEG = 16 * 1024, 7
-    waves = [pkg.ggml.synth_audio(N, 640 + i) for i in range(NSEG)]
-    ins = [torch.from_numpy(np.ascontiguousarray(w.T).ravel()).cuda() for w in waves]
-    res = {}
-    for slots in ("2", "3"):
-        monkeypatch.setenv("UMX_SLOTS", slots)
-        eng = pkg.Engine(targets, 128, N)
-        assert eng.pipeline_depth() == int(slots)
-        serial = [eng.infer_segment(w) for w in waves]
-        eng.stream_reset()
-        o = [[torch.empty(2 * N, dtype=torch.float32, device="cuda") for _ in range(4)] for _ in range(NSEG)]
-        torch.cuda.synchronize()
-        for i in range(NSEG):
-            eng.infer_segment_device(ins[i].data_ptr(), N, [x.data_ptr() for x in o[i]])
-        eng.sync()
-        for i in range(NSEG):
-            for t in range(4):
-                assert (o[i][t].cpu().numpy() == np.ascontiguousarray(serial[i][t].T).ravel()).all(), (slots, i, t)
-        res[slots] = (serial, eng.stream_get())
-        eng.close()
-    assert (res["2"][1] == res["3"][1]).all()
-    for i in range(NSEG):
-        for t in range(4):
-            assert (res["2"][0][i][t] == res["3"][0][i][t]).all()

@@ -117,24 +117,35 @@ template <int MODE> static void run(const char *what, const unsigned short *src,
 
 int main()
 {
-    const int row_elems = 1024, rows = 256 * 256; // 128 MB of source: 256 rows x 2 KB per workgroup, swept again and again
+    const int rows = 256 * 256; // 256 rows per workgroup, swept again and again (L2 / MALL resident)
     unsigned short *src;
     unsigned long long *d_cyc;
     unsigned *d_sink;
-    hipMalloc(&src, (size_t)rows * row_elems * 2 + 65536);
-    hipMemset(src, 0x11, (size_t)rows * row_elems * 2 + 65536);
+    hipMalloc(&src, (size_t)rows * 3072 * 2 + 65536);
+    hipMemset(src, 0x11, (size_t)rows * 3072 * 2 + 65536);
     hipMalloc(&d_cyc, 256 * 8);
     hipMalloc(&d_sink, 4);
     const int trips = 20000;
     printf("# tools/lds_probe: PP_LOAD's fragment reads (20 swizzled ds_read_b128 = 20 KiB per wave and trip) and PP_DMA's 48 KB per trip\n");
-    run<0>("mode 0: eight waves read", src, row_elems, trips, d_cyc, d_sink);
-    run<1>("mode 1: four waves (one per SIMD) read", src, row_elems, trips, d_cyc, d_sink);
-    run<3>("mode 3: LDS-DMA alone (group 0, 48 KB per trip)", src, row_elems, trips, d_cyc, d_sink);
-    run<2>("mode 2: group 1 reads beside group 0's LDS-DMA", src, row_elems, trips, d_cyc, d_sink);
-    run<4>("mode 4: eight waves read, group 0 also issues the DMA", src, row_elems, trips, d_cyc, d_sink);
-    run<5>("mode 5: LDS-DMA alone, dealt to all eight waves", src, row_elems, trips, d_cyc, d_sink);
-    run<6>("mode 6: LDS-DMA alone (group 0), 8 rows x 128 B pieces", src, row_elems, trips, d_cyc, d_sink);
-    run<7>("mode 7: LDS-DMA alone (group 0), 1 KiB contiguous pieces", src, row_elems, trips, d_cyc, d_sink);
-    run<8>("mode 8: LDS-DMA alone, 8 rows x 128 B pieces, all eight waves", src, row_elems, trips, d_cyc, d_sink);
+    {
+        const int row_elems = 1024;
+        run<0>("mode 0: eight waves read", src, row_elems, trips, d_cyc, d_sink);
+        run<1>("mode 1: four waves (one per SIMD) read", src, row_elems, trips, d_cyc, d_sink);
+        run<3>("mode 3: LDS-DMA alone (group 0, 48 KB per trip)", src, row_elems, trips, d_cyc, d_sink);
+        run<2>("mode 2: group 1 reads beside group 0's LDS-DMA", src, row_elems, trips, d_cyc, d_sink);
+        run<4>("mode 4: eight waves read, group 0 also issues the DMA", src, row_elems, trips, d_cyc, d_sink);
+        run<5>("mode 5: LDS-DMA alone, dealt to all eight waves", src, row_elems, trips, d_cyc, d_sink);
+        run<6>("mode 6: LDS-DMA alone (group 0), 8 rows x 128 B pieces", src, row_elems, trips, d_cyc, d_sink);
+        run<7>("mode 7: LDS-DMA alone (group 0), 1 KiB contiguous pieces", src, row_elems, trips, d_cyc, d_sink);
+        run<8>("mode 8: LDS-DMA alone, 8 rows x 128 B pieces, all eight waves", src, row_elems, trips, d_cyc, d_sink);
+    }
+    // the row pitch of the source (the planes' K): do the 16 rows of a piece spread over the L2 channels?
+    printf("# mode 5 (16 rows x 64 B pieces, all eight waves) by the row pitch of the source\n");
+    for (int row_elems : {1024, 1056, 1088, 1152, 1536, 2048, 2080, 2112, 2976, 3008})
+    {
+        char what[96];
+        snprintf(what, sizeof what, "mode 5, row pitch %d B", row_elems * 2);
+        run<5>(what, src, row_elems, trips, d_cyc, d_sink);
+    }
     return 0;
 }

@@ -1117,15 +1117,10 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     if (int rc = dalloc(&backup, (size_t)kBackupCalls * 3 * state_floats() * B))
         return rc;
     lsync_words = LSTM_SYNC_HEADER_WORDS + std::max(granule_count(S) * 2, lstm_batched ? lstmb_granule_words(Hl) * ((B + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS) : (size_t)0);
-    if (const char *e = getenv("UMX_LSTM_GATE_WAVE"))
-        lstm_threads = atoi(e) ? LSTM_PERSISTENT_THREADS : LSTM_THREADS;
     // Two slots.  (Three were tried for single-track contexts in round 3 -- a third segment in flight has its front stage
     // done by the time an LSTM grid retires, so that two grids would be resident all the time: 7.57 ms per segment against
-    // 6.70 with two; the grids and the GEMM blocks beside them only slow each other down, avg LSTM launch 3.03 -> 3.79 ms.
-    // UMX_SLOTS=3 keeps the experiment available.)
+    // 6.70 with two; the grids and the GEMM blocks beside them only slow each other down, avg LSTM launch 3.03 -> 3.79 ms.)
     nslots = 2;
-    if (const char *e = getenv("UMX_SLOTS"))
-        nslots = std::min(std::max(atoi(e), 2), (int)kMaxSlots);
     for (int si = 0; si < nslots; ++si)
     {
         Slot &sl = slot[si];
@@ -1255,9 +1250,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         UMX_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         n_cus = cus;
         lstm_capacity = per_cu * cus;
-        if (const char *e = getenv("UMX_LSTM_NO_OVERLAP")) // testing: never run two LSTM grids at once
-            if (atoi(e))
-                lstm_capacity = std::min(lstm_capacity, 2 * 8 * S - 1);
         if (lstm_batched)
         {
             // the batched kernel: worst-case dynamic LDS (16 lanes), both activation flavours
@@ -1315,10 +1307,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
         {
             const int wi_lds = 4 * FFT_LDS_ELEMS * (int)sizeof(float2); // 139,264 (NSRC = 4; 2 and 1 need less)
-            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
-            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
-            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds / 2));
-            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds / 2));
+            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
+            UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
         }
 #define UMX_GP_ATTR(MODE)                                                                                              \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(2, 2, 1))); \
@@ -1922,14 +1912,8 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
     }
     else
     {
-        static const int ns = getenv("UMX_WIENER_NS") ? atoi(getenv("UMX_WIENER_NS")) : 2; // sources per thread (measured: 4: 0.151, 2: 0.128, 1: 0.131 ms per track)
-        const dim3 g((NBINS + 63) / 64, nchunk * lanes.count, 4 / (ns == 1 || ns == 2 ? ns : 4));
-        if (ns == 1)
-            hipLaunchKernelGGL(wiener_stats4_kernel<1>, g, dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
-        else if (ns == 2)
-            hipLaunchKernelGGL(wiener_stats4_kernel<2>, g, dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
-        else
-            hipLaunchKernelGGL(wiener_stats4_kernel<4>, g, dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
+        // two sources per thread (measured: 4 per thread 0.151, 2: 0.128, 1: 0.131 ms per track)
+        hipLaunchKernelGGL(wiener_stats4_kernel<2>, dim3((NBINS + 63) / 64, nchunk * lanes.count, 2), dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
         hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4, lanes.count), dim3(256), 0, st, L0.wpart, T, L0.Rc, wiener_fused ? nullptr : L0.R, lanes, ls);
         if (!wiener_fused)
             for (int i = 0; i < lanes.count; ++i)
@@ -1972,15 +1956,14 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
         // runs: a few rounds of workgroups over the chip (one workgroup per CU), at least three frames each
         const int runs = std::max(1, std::min(T / 8, (4 * n_cus + lanes.count - 1) / lanes.count));
         const int run_len = std::max(3, (T + runs - 1) / runs), nruns = (T + run_len - 1) / run_len;
-        static const int nsrc = getenv("UMX_WIENER_NSRC") ? atoi(getenv("UMX_WIENER_NSRC")) : 4; // sources per workgroup (tuning knob)
-#define UMX_WI(W, NS)                                                                                                \
-    hipLaunchKernelGGL((wiener_istft_kernel<W, NS>), dim3(nruns, 4 / NS, lanes.count), dim3(256 * NS), (size_t)NS * FFT_LDS_ELEMS * sizeof(float2), st, \
-                       L0.spec, wm0, T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, ls, run_len, oo)
-        const bool nowi = flags & UMX_FLAG_NO_WIENER;
-        if (nsrc == 1) { if (nowi) UMX_WI(false, 1); else UMX_WI(true, 1); }
-        else if (nsrc == 2) { if (nowi) UMX_WI(false, 2); else UMX_WI(true, 2); }
-        else { if (nowi) UMX_WI(false, 4); else UMX_WI(true, 4); }
-#undef UMX_WI
+        // one 1024-thread workgroup per run, all four sources (two / one source per workgroup, i.e. more workgroups per CU that
+        // each repeat the source-independent part, measured 1.7x / 2.7x slower in round 2)
+        if (flags & UMX_FLAG_NO_WIENER)
+            hipLaunchKernelGGL((wiener_istft_kernel<false>), dim3(nruns, 1, lanes.count), dim3(1024), (size_t)4 * FFT_LDS_ELEMS * sizeof(float2), st, L0.spec, wm0,
+                               T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, ls, run_len, oo);
+        else
+            hipLaunchKernelGGL((wiener_istft_kernel<true>), dim3(nruns, 1, lanes.count), dim3(1024), (size_t)4 * FFT_LDS_ELEMS * sizeof(float2), st, L0.spec, wm0,
+                               T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, ls, run_len, oo);
         stage_range(ST_OLA);
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));
         hipLaunchKernelGGL(wiener_ola_edges_kernel, dim3(3 * HOP / 256, nruns * 4, lanes.count), dim3(256), 0, st, L0.frames, ls.frames, T, run_len, oo);
@@ -2081,9 +2064,8 @@ int umx_hip_ctx::infer_batch(int nb, const float *const *audio_dev, const int *n
     // Track-batched contexts: the kernels of consecutive calls run one after the other.  Their workgroups take whole CUs (plane
     // GEMM, batched LSTM, fused Wiener kernel), so kernels of two calls side by side only wait for each other's CUs: since the
     // streaming kernels cover all lanes in one launch the serial step is the faster one (32 lanes: 75.4 against 76.3 ms).  The two
-    // slots remain for the buffers: uploads and downloads of neighbouring calls still overlap these kernels.  UMX_OVERLAP=1: as before.
-    static const bool overlap_calls = getenv("UMX_OVERLAP") && atoi(getenv("UMX_OVERLAP")) != 0;
-    if (lstm_batched && !overlap_calls && prev.used && &prev != &sl)
+    // slots remain for the buffers: uploads and downloads of neighbouring calls still overlap these kernels.
+    if (lstm_batched && prev.used && &prev != &sl)
         UMX_HIP_CHECK(hipStreamWaitEvent(st, prev.ev[ST_COUNT], 0));
     if (int rc = stage_front(sl, st, nb, audio_dev, n, active, nact))
         return rc;
@@ -2226,8 +2208,6 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
     if (!trk_acc_ev[0])
         for (int s = 0; s < nslots; ++s)
             UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
-    const bool timing = getenv("UMX_TRACK_TIMING") != nullptr;
-    const auto tt0 = std::chrono::steady_clock::now();
     // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
     UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats() * nt));
     clear_used();
@@ -2242,7 +2222,6 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
     }
     UMX_HIP_CHECK(hipDeviceSynchronize());
 
-    const auto tt1 = std::chrono::steady_clock::now();
     const int stride = (int)((1 - 0.25f) * N); // umx.cpp:181, inference.hpp:15
     const float total_reps = std::ceil((float)L2max / (float)stride); // umx.cpp:208 (of the longest track)
     float done = 0.f;
@@ -2314,7 +2293,6 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
         if (progress)
             progress(done, progress_user);
     }
-    const auto tt2 = std::chrono::steady_clock::now();
     hipError_t cerr = hipSuccess;
     for (const Region &rg : regions) // umx.cpp:136-147: drop the shift
     {
@@ -2338,13 +2316,6 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
     UMX_HIP_CHECK(hipGetLastError());
     if (int rc = umx_hip_sync(this)) // surfaces a persistent-kernel timeout
         return rc;
-    if (timing)
-    {
-        const auto tt3 = std::chrono::steady_clock::now();
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[umx track] %d track(s), longest %d samples: clear+upload %.1f ms, queuing %d segment calls %.1f ms, segments + overlapped "
-                        "download %.1f ms\n", nt, L2max, ms(tt0, tt1), iseg, ms(tt1, tt2), ms(tt2, tt3));
-    }
     return UMX_OK;
 }
 

@@ -47,25 +47,10 @@ constexpr int LSTMB_GROUP_TRACKS = 16; // the matrix instruction's N
 // published and needs one hand-off latency; the other waves come straight from the barrier and have the whole gate
 // phase in front of them -- polling through it would only load the L2 (every failed attempt is 8 x 16 B per lane)
 // and take issue slots from the gate wave sharing their SIMD.
-#ifndef LSTMB_DELAY_GATE
 #define LSTMB_DELAY_GATE 0
-#endif
-#ifndef LSTMB_DELAY_IDLE
 #define LSTMB_DELAY_IDLE 24
-#endif
-#ifndef LSTMB_DEFER_OUT
-#define LSTMB_DEFER_OUT 1
-#endif
-#ifndef LSTMB_PROF_WAVE
 #define LSTMB_PROF_WAVE 4 // the second wave the in-kernel profiler reports (beside wave 0): 4..7 = a wave without gate work
-#endif
-#ifndef LSTMB_HSUM_GRANULE
-#define LSTMB_HSUM_GRANULE 0 // 0: sum_k h'_k from an all-ones matrix tile (4 of a wave's 20 matrix instructions); 1: from pair sums that travel
-                             // in the granules' free dword + two lane exchanges -- 20 % fewer matrix-pipe cycles, 1.5 % SLOWER (A/B round 3)
-#endif
-#ifndef LSTMB_RETRY_SLEEP
 #define LSTMB_RETRY_SLEEP 1 // x64 cycles between failed polls
-#endif
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 struct LstmBArgs
@@ -117,9 +102,7 @@ template <bool FAST> __device__ __forceinline__ void granule_store16(__amdgpu_bu
 // lanes of a 16-lane read group differ in the TRACK and read the same 16 bytes of 16 different (row, track) blocks: at a
 // pitch of 256 bytes all of them hit the same four banks (a 16-way conflict: 21 % of the LDS cycles of round 2's kernel,
 // the only kernel of the profile with any); 16 bytes of padding spread them over all 64 banks.
-#ifndef LSTMB_RING_PITCH_BYTES
 #define LSTMB_RING_PITCH_BYTES 272
-#endif
 constexpr int LSTMB_RING_PITCH = LSTMB_RING_PITCH_BYTES;
 __host__ __device__ inline size_t lstmb_lds_bytes(int nbp, int bulk)
 {
@@ -151,34 +134,11 @@ template <int NDW> __device__ __forceinline__ float2v tree_sum2(const float2v (&
     return p[0];
 }
 
-// WQ form: sum_k h'_k over a wave's k-range, the factor of the weight tensor's offset (model.cpp:610-616 applied to the
-// sum).  Rounds 2's kernels took it from a fifth M tile whose A operand was all ones -- 4 of a wave's 20 matrix
-// instructions, in one dependent chain.  Now the PRODUCER hands it over: the fourth dword of a granule (free so far) holds
-// the pair's (h1 + h2) + (h1' + h2') as fp32 (each bracket is exact: two fp16 planes of one value), the consumer adds the
-// eight granules it loads anyway and folds the four 8-unit groups of the wave with two lane exchanges.  Fixed order, the
-// same in every kernel that runs the batched recurrence, so a track's bits still do not depend on kernel, group or lane.
-__device__ __forceinline__ float f16_bits_to_f32(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
-__device__ __forceinline__ float pair_hsum(unsigned even12, unsigned odd12) // x12 = h1 bits | h2 bits << 16 of one unit
-{
-    return (f16_bits_to_f32(even12 & 0xffffu) + f16_bits_to_f32(even12 >> 16)) + (f16_bits_to_f32(odd12 & 0xffffu) + f16_bits_to_f32(odd12 >> 16));
-}
-__device__ __forceinline__ float fold_q(float x) // sum over the four 8-unit groups (lanes n, n + 16, n + 32, n + 48): every lane gets it
-{
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    return x;
-}
-// the same sum for a fragment that comes from the fp32 stream state (first step of a launch): planes p1 / p2 of 8 units
-__device__ __forceinline__ float planes_hsum(const uint4 &p1, const uint4 &p2)
-{
-    const unsigned a[4] = {p1.x, p1.y, p1.z, p1.w}, b[4] = {p2.x, p2.y, p2.z, p2.w};
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) // pair i = units 2i, 2i + 1: exactly what the producer of a granule computes
-        s += pair_hsum((a[i] & 0xffffu) | (b[i] << 16), (a[i] >> 16) | (b[i] & 0xffff0000u));
-    return s;
-}
-
+// WQ form: sum_k h'_k over a wave's k-range (the factor of the weight tensor's offset, model.cpp:610-616 applied to the sum) comes
+// out of a fifth M tile whose A operand is all ones -- 4 of a wave's 20 matrix instructions.  (Round 3 measured the alternative:
+// the pair sums (h1 + h2) + (h1' + h2') travelling in the granules' free fourth dword, added by the consumer and folded over the
+// four 8-unit groups with two lane exchanges: 20 % fewer matrix-pipe cycles, 1.5 % SLOWER -- two dependent lane exchanges on the
+// turn's critical path cost more than four queued matrix instructions on an idle pipe.  Removed in round 4; the dword is zero.)
 template <int HL, bool WQ, bool FAST, bool PRECISE>
 __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int slice, unsigned char *smem, int *abort_flag)
 {
@@ -254,7 +214,6 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
     }
     // ---- h_{t_begin - 1} from the fp32 stream state, split like a published granule
     bf16x8 hf[KSW][3];
-    [[maybe_unused]] float sumh = 0.f; // LSTMB_HSUM_GRANULE: this lane's share of sum_k h'_k (its 8 units x KSW K steps)
 #pragma unroll
     for (int ks = 0; ks < KSW; ++ks)
     {
@@ -264,10 +223,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             hv[j] = (dot_wave && lane_on) ? a.state[st_h + (w * KSW + ks) * 32 + 8 * q + j] : 0.f;
         uint4 p1, p2, p3 = make_uint4(0u, 0u, 0u, 0u);
         if (WQ)
-        {
             split2_f16(hv, HSCALE, p1, p2);
-            sumh += planes_hsum(p1, p2);
-        }
         else
             split3(hv, p1, p2, p3);
         hf[ks][0] = as_bf16x8(p1);
@@ -314,9 +270,6 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 
     for (int step = t_begin; step < t_end; ++step)
     {
-#if !LSTMB_DEFER_OUT
-        const int t = dir == 0 ? step : T - 1 - step;
-#endif
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (prof)
             c0 = clock64();
@@ -384,8 +337,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                     __builtin_amdgcn_s_sleep(LSTMB_RETRY_SLEEP);
                 }
                 prof_spins = spins;
-                // granule i = {tag, h1 of units (2i, 2i+1), h2 pair, h3 pair | WQ: the pair's sum}: the payload dwords are the fragments' dwords
-                sumh = 0.f;
+                // granule i = {tag, h1 of units (2i, 2i+1), h2 pair, h3 pair | WQ: 0}: the payload dwords are the fragments' dwords
 #pragma unroll
                 for (int ks = 0; ks < KSW; ++ks)
                 {
@@ -394,8 +346,6 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                     hf[ks][0] = as_bf16x8(make_uint4(g0.y, g1.y, g2.y, g3.y));
                     hf[ks][1] = as_bf16x8(make_uint4(g0.z, g1.z, g2.z, g3.z));
                     hf[ks][2] = as_bf16x8(make_uint4(g0.w, g1.w, g2.w, g3.w));
-                    if (WQ)
-                        sumh += ((__uint_as_float(g0.w) + __uint_as_float(g1.w)) + __uint_as_float(g2.w)) + __uint_as_float(g3.w);
                 }
                 // every gate wave of this workgroup is past iteration step - 2 (it has crossed the barrier of step - 1),
                 // so ring rows <= step - 2 may be replaced: rows [step-1+bulk, step-1+2 bulk) take the slots of
@@ -406,10 +356,8 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             if (prof)
                 c1 = clock64();
             floatx4 acc[4];
-#if !LSTMB_HSUM_GRANULE
             floatx4 accH = {0.f, 0.f, 0.f, 0.f};
             const f16x8 ones16 = __builtin_bit_cast(f16x8, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));
-#endif
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
                 acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -425,13 +373,11 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 // smaller term first
                 LSTMB_TERM16(1)
                 LSTMB_TERM16(0)
-#if !LSTMB_HSUM_GRANULE
 #pragma unroll
                 for (int ph = 1; ph >= 0; --ph)
 #pragma unroll
                     for (int ks = 0; ks < KSW; ++ks)
                         accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones16, __builtin_bit_cast(f16x8, hf[ks][ph]), accH, 0, 0, 0);
-#endif
             }
             else
             {
@@ -444,11 +390,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             }
 #undef LSTMB_TERM
 #undef LSTMB_TERM16
-#if LSTMB_HSUM_GRANULE
-            const float hsum_wave = WQ ? fold_q(sumh) : 0.f; // (every lane takes part in the exchange)
-#else
             const float hsum_wave = WQ ? accH[0] : 0.f;
-#endif
             if (n < nbp)
             {
                 float4 *pw = part + ((size_t)(((step & 1) * 8 + w) * 4) * 4 + q) * nbp + n;
@@ -461,12 +403,10 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                                                   : make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
             }
         }
-#if LSTMB_DEFER_OUT
         // the output row of the PREVIOUS step goes out here, behind the polls: vector memory operations complete in
         // order, and a store queued in front of the poll loads would sit on the hand-off's critical path
         if (gate_wave && lane_on && step > t_begin)
             outp[(size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast; // lstm.cpp:163-164,170-171
-#endif
         // W_ih x + b_ih of this lane's unit and track (in the ring since at least one barrier ago)
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gate_wave && n < nbp)
@@ -480,9 +420,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             c3 = clock64();
         if (gate_wave && n < nbp)
         {
-#if LSTM_GATE_PRIO
-            __builtin_amdgcn_s_setprio(LSTM_GATE_PRIO);
-#endif
+            __builtin_amdgcn_s_setprio(1); // the serial gate phase wins issue arbitration (measured: -1.5 % per segment pipelined)
             // the NDW k-range partials, summed in a fixed tree, two gates per (unswizzled) packed add
             float2v pa[8], pb[8];
 #pragma unroll
@@ -542,16 +480,11 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 if ((q & 1) == 0) // publish the pair (this unit, the next), tagged step + 1
                 {
                     const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u),
-                                                WQ ? __float_as_uint(pair_hsum(mine12, other12)) : (b3 | (other3 << 16)));
+                                                WQ ? 0u : (b3 | (other3 << 16)));
                     granule_store16<FAST>(gran_rs, (int)(lstmb_granule_index(step & 1, chain, unit, n, HL, nbp) * 16), gv);
                 }
-#if !LSTMB_DEFER_OUT
-                outp[(size_t)t * ldo] = h; // lstm.cpp:163-164,170-171
-#endif
             }
-#if LSTM_GATE_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         }
         if (prof)
         {
@@ -566,10 +499,8 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
     }
     if (gate_wave && lane_on) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
     {
-#if LSTMB_DEFER_OUT
         if (t_end > t_begin)
             outp[(size_t)(dir == 0 ? t_end - 1 : T - t_end) * ldo] = hlast;
-#endif
         a.state_out[st_h + unit] = hlast;
         a.state_out[st_c + unit] = c;
     }

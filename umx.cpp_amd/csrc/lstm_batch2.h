@@ -22,7 +22,7 @@
 // turn ahead, between the two halves of the current group's matrix instructions, so that the poll's L2 round trip would be
 // off the turn (8.8 -> 10.7 ms per 32-lane launch, 12.8 -> 14.1 ms for 48 lanes: the granules of the slowest of the chain's
 // 32 workgroups are not there yet, and a failed first attempt costs a second round trip; round 2 saw the same a whole turn
-// ahead); sum_k h' from pair sums carried in the granules' free dword instead of the all-ones tile (LSTMB_HSUM_GRANULE:
+// ahead); sum_k h' from pair sums carried in the granules' free dword instead of the all-ones tile (round 3:
 // matrix-pipe cycles -20 %, time +1.5 %: two dependent lane exchanges cost more than four queued matrix instructions).
 // Kept: the W_ih-row ring at a pitch of 272 bytes (SQ_LDS_BANK_CONFLICT 1.5e8 -> 2e7 per launch; same time).
 #pragma once
@@ -136,9 +136,6 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
             if (dot_wave)
             {
                 f16x8 hf[KSW][2];
-#if LSTMB_HSUM_GRANULE
-                float sumh = 0.f; // this lane's share of sum_k h'_k (lstm_batch.h: pair sums travel in the granules)
-#endif
                 if (step == t_begin)
                 {
                     // h_{t_begin - 1} from the fp32 stream state, split like a published granule
@@ -151,9 +148,6 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                             hv[j] = lane_on[g] ? a.state[st_h[g] + (w * KSW + ks) * 32 + 8 * q + j] : 0.f;
                         uint4 p1, p2;
                         split2_f16(hv, HSCALE, p1, p2);
-#if LSTMB_HSUM_GRANULE
-                        sumh += planes_hsum(p1, p2);
-#endif
                         hf[ks][0] = __builtin_bit_cast(f16x8, p1);
                         hf[ks][1] = __builtin_bit_cast(f16x8, p2);
                     }
@@ -206,9 +200,6 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                                     g3 = lane_on[g] ? v[ks][3] : z;
                         hf[ks][0] = __builtin_bit_cast(f16x8, make_uint4(g0.y, g1.y, g2.y, g3.y));
                         hf[ks][1] = __builtin_bit_cast(f16x8, make_uint4(g0.z, g1.z, g2.z, g3.z));
-#if LSTMB_HSUM_GRANULE
-                        sumh += ((__uint_as_float(g0.w) + __uint_as_float(g1.w)) + __uint_as_float(g2.w)) + __uint_as_float(g3.w);
-#endif
                     }
                     // ring rows <= step - 2 may be replaced (every gate wave has read row step - 1 before the barriers of
                     // step - 1): rows [step-1+bulk, step-1+2 bulk) take the slots of [step-1-bulk, step-1); first read
@@ -227,16 +218,12 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
                             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[mt][ks], hf[ks][ph], acc[mt], 0, 0, 0);
-#if LSTMB_HSUM_GRANULE
-                const float hs = wof2 * fold_q(sumh);
-#else
 #pragma unroll
                 for (int ph = 1; ph >= 0; --ph)
 #pragma unroll
                     for (int ks = 0; ks < KSW; ++ks)
                         accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, hf[ks][ph], accH, 0, 0, 0);
                 const float hs = wof2 * accH[0];
-#endif
                 float4 *pw = part + ((size_t)((g * 8 + w) * 4) * 4 + q) * NB + n;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -294,7 +281,7 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                     if ((q & 1) == 0) // publish the pair (this unit, the next), tagged step + 1
                     {
                         const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u),
-                                                    LSTMB_HSUM_GRANULE ? __float_as_uint(pair_hsum(mine12, other12)) : 0u);
+                                                    0u);
                         granule_store16<FAST>(gran_rs, (int)(g * group_bytes + lstmb_granule_index(step & 1, chain, unit, n, HL, NB) * 16), gv);
                     }
                 }

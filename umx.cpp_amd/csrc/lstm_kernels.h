@@ -55,10 +55,6 @@ __device__ __forceinline__ float hadd2(float2v v)
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
     return r;
 }
-#ifndef LSTM_DOT_PK
-#define LSTM_DOT_PK 1 // 1: rotations (2m, 2m+1) feed one v_pk_fma_f32 (even-n / odd-n partial sums); 0: 64 v_fmac_f32 +
-                      // 15 DPP movs; 2: 64 v_fmac_f32_dpp (rotation folded into the FMA's src0, same order as 0)
-#endif
 
 struct LstmArgs
 {
@@ -82,9 +78,7 @@ struct LstmArgs
 };
 
 constexpr int LSTM_SYNC_HEADER_WORDS = 32; // census[8], arrivals, pad -> granules start 128-byte aligned
-#ifndef LSTM_SLICE_STRIDE
 #define LSTM_SLICE_STRIDE 16 // granules (8 B each) between the 16-granule lines of consecutive slices
-#endif
 // granule index of (slot, chain, hidden unit k): one 128-byte line per producer slice, lines spread with
 // LSTM_SLICE_STRIDE so that a chain's lines do not pile up on one L2 channel
 __host__ __device__ inline size_t granule_index(int slot, int chain, int k, int S)
@@ -207,7 +201,6 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
         float pr[4];
         for (int r = 0; r < 4; ++r)
         {
-#if LSTM_DOT_PK == 1
             float acc_e = 0.f, acc_o = 0.f; // even / odd rotations: the two halves of v_pk_fma_f32
             for (int n = 0; n < 16; n += 2)
             {
@@ -217,15 +210,6 @@ template <bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS) void lstm_ste
                 acc_o = fmaf(whh_at(a, wchain, Wc0 + (size_t)ko * 64), hs[ko], acc_o);
             }
             pr[r] = acc_e + acc_o;
-#else
-            float acc = 0.f;
-            for (int n = 0; n < 16; ++n)
-            {
-                const int k = 64 * w + 16 * r + ((u + rdir * n) & 15);
-                acc = fmaf(whh_at(a, wchain, Wc0 + (size_t)k * 64), hs[k], acc);
-            }
-            pr[r] = acc;
-#endif
         }
         partial = (pr[0] + pr[2]) + (pr[1] + pr[3]);
     }
@@ -284,29 +268,13 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then abort the launch
-#ifndef LSTM_SETPRIO
-#define LSTM_SETPRIO 0 // measured: no effect on MI355X with GEMM waves of the other slot co-resident
-#endif
-#ifndef LSTM_POLLS_IN_FLIGHT
 #define LSTM_POLLS_IN_FLIGHT 1 // measured best once two LSTM grids share the chip (2: -3 %, 3: -5 %)
-#endif
-#ifndef LSTM_PROF_WAVE
 #define LSTM_PROF_WAVE 1 // the dot wave the in-kernel profiler reports beside the gate wave
-#endif
-#ifndef LSTM_P_BULK
 #define LSTM_P_BULK 16 // W_ih x + b_ih rows fetched per bulk (multiple of 8, power of two)
-#endif
 #define LSTM_P_RING (2 * LSTM_P_BULK)
-#ifndef LSTM_GATE_PRIO
-#define LSTM_GATE_PRIO 1 // s_setprio of the gate wave during its serial gate phase (measured: -1.5 % per segment pipelined)
-#endif
-#ifndef LSTM_GATE_POLL_DELAY
 #define LSTM_GATE_POLL_DELAY 0 // x64 cycles the gate wave waits after publishing before its own first poll
                                // (measured 0..4: 0 is best, its first poll already succeeds)
-#endif
-#ifndef LSTM_POLL_DELAY
 #define LSTM_POLL_DELAY 8 // x64 shader cycles a dot wave sleeps after the barrier before its first poll
-#endif
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -366,7 +334,6 @@ __device__ __forceinline__ void lstm_census(unsigned *sync, unsigned *status_, i
 }
 
 // KPW = Hl/8 = k-range (and granules) per wave; KPW <= 64, even.
-#if LSTM_DOT_PK == 1
 // register-resident W_hh slice of one lane: rotation pairs (2m, 2m+1) are adjacent registers
 struct WSlice
 {
@@ -409,46 +376,6 @@ template <int N> struct DotDpp
             acc[cc] = hadd2(acc2[cc]);
     }
 };
-#else
-struct WSlice
-{
-    float v[16][4];
-    __device__ __forceinline__ void set(int n, const float4 &x)
-    {
-        v[n][0] = x.x;
-        v[n][1] = x.y;
-        v[n][2] = x.z;
-        v[n][3] = x.w;
-    }
-};
-template <int N> struct DotDpp
-{
-    // acc[cc] += W[N][cc] * h(rotated by N lanes inside the row), for N = 15 .. 0 recursively
-    static __device__ __forceinline__ void run(const WSlice &W, int hbits, float (&acc)[4])
-    {
-        DotDpp<N - 1>::run(W, hbits, acc);
-#if LSTM_DOT_PK == 2
-        if constexpr (N > 0)
-        {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-                asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf"
-                             : "+v"(acc[cc])
-                             : "v"(hbits), "v"(W.v[N][cc]), "n"(N));
-            return;
-        }
-#endif
-        const float hr = __int_as_float(dpp_row_ror<N>(hbits));
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-            acc[cc] = fmaf(W.v[N][cc], hr, acc[cc]);
-    }
-};
-template <> struct DotDpp<-1>
-{
-    static __device__ __forceinline__ void run(const WSlice &, int, float (&)[4]) {}
-};
-#endif
 template <int N> struct KidxDpp
 {
     static __device__ __forceinline__ void run(int lane_k, int (&kidx)[16])
@@ -689,9 +616,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             c3 = clock64();
         if (gate_wave)
         {
-#if LSTM_GATE_PRIO
-            __builtin_amdgcn_s_setprio(LSTM_GATE_PRIO); // the serial gate phase wins issue arbitration against dot waves
-#endif
+            __builtin_amdgcn_s_setprio(1); // the serial gate phase wins issue arbitration against dot waves
             float(*pq)[64] = *(part + (step & 1));
             const float s = ((pq[0][l] + pq[1][l]) + (pq[2][l] + pq[3][l])) + ((pq[4][l] + pq[5][l]) + (pq[6][l] + pq[7][l]));
             const float pre = (pbuf[step & (LSTM_P_RING - 1)][l] + s) + bh;
@@ -705,9 +630,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 outp[(size_t)t * ldo] = h;
                 hlast = h;
             }
-#if LSTM_GATE_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         }
         if (prof)
         {
@@ -739,11 +662,6 @@ template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_TH
     __shared__ int s_ctl[4]; // chain, slice, fast, abort
     const int tid = threadIdx.x;
     const int nwg = gridDim.x, S = a.S;
-#if LSTM_SETPRIO
-    // latency-critical waves: win issue arbitration against co-resident GEMM / streaming waves of the
-    // other pipeline slot (those are throughput-bound and lose little)
-    __builtin_amdgcn_s_setprio(3);
-#endif
     if (tid == 0)
         lstm_census(a.sync, a.status, S, nwg, a.force_safe, s_ctl);
     __syncthreads();

@@ -24,23 +24,12 @@
 #ifndef WI_PROFILE
 #define WI_PROFILE 0 // 1: one workgroup per launch prints where the cycles of a frame go (timing build)
 #endif
-#ifndef WI_STREAM_LOADS
-#define WI_STREAM_LOADS 1
-#endif
 
 namespace umx
 {
 
-// NSRC = sources per workgroup (4: one workgroup per frame as described above; 2 / 1: grid.y = 2 / 4 workgroups per frame,
-// each repeating phase 1's source-independent part for its own bins -- the second reads hit the L2 -- in exchange for
-// 2 / 4 workgroups per CU whose phases overlap)
-// rc[s] for a run-time s without indexing the array (it stays in registers)
-__device__ __forceinline__ float4 sel4(int s, const float4 (&r)[4])
-{
-    return make_float4(s == 0 ? r[0].x : s == 1 ? r[1].x : s == 2 ? r[2].x : r[3].x, s == 0 ? r[0].y : s == 1 ? r[1].y : s == 2 ? r[2].y : r[3].y,
-                       s == 0 ? r[0].z : s == 1 ? r[1].z : s == 2 ? r[2].z : r[3].z, s == 0 ? r[0].w : s == 1 ? r[1].w : s == 2 ? r[2].w : r[3].w);
-}
-
+// (Two or one source per workgroup -- 2 / 4 workgroups per frame, each repeating phase 1's source-independent part, in exchange for
+// more workgroups per CU whose phases overlap -- measured 1.7x / 2.7x slower in round 2; the template parameter is gone.)
 // streamed-once inputs: non-temporal loads, so that they do not push the stems' read-modify-write lines out of the L2
 typedef float wi_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 ld_stream(const float2 *p)
@@ -50,19 +39,19 @@ __device__ __forceinline__ float2 ld_stream(const float2 *p)
 }
 __device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
 
-template <bool WIENER, int NSRC>
-__global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
+template <bool WIENER>
+__global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
                                                                   const unsigned *__restrict__ maxabs_bits,
                                                                   const float *__restrict__ Rc, const float *__restrict__ window,
                                                                   const float *__restrict__ nw, const float2 *__restrict__ tw1,
                                                                   const float2 *__restrict__ tw2, float2 *__restrict__ frames,
                                                                   float2 *__restrict__ y_dbg, WienerStrides ls, int run_len, OlaOut out)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [NSRC][FFT_LDS_ELEMS]
-    constexpr int WI_THREADS = 256 * NSRC;
+    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [4 sources][FFT_LDS_ELEMS]
+    constexpr int NSRC = 4, WI_THREADS = 256 * NSRC;
     const LaneSet &lanes = out.lanes;
     {
-        const int ln = lanes.id[blockIdx.z]; // grid (runs of run_len frames, 4 / NSRC, lanes): the pointers are lane 0's
+        const int ln = lanes.id[blockIdx.z]; // grid (runs of run_len frames, 1, lanes): the pointers are lane 0's
         spec += (size_t)ln * ls.spec;
         Rc += (size_t)ln * ls.rc;
         frames += (size_t)ln * ls.frames;
@@ -73,7 +62,7 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
         for (int s = 0; s < 4; ++s)
             mags.m[s] += (size_t)ln * ls.mag;
     }
-    const int src0 = NSRC * blockIdx.y;
+    constexpr int src0 = 0;
     const int tid = threadIdx.x;
     const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;
     const int f0 = (int)blockIdx.x * run_len, f1 = min(T, f0 + run_len);
@@ -105,14 +94,14 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
             break;
         const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
         const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
-        const float2 X0 = WI_STREAM_LOADS ? ld_stream(spec + i0) : spec[i0], X1 = WI_STREAM_LOADS ? ld_stream(spec + i1) : spec[i1];
+        const float2 X0 = ld_stream(spec + i0), X1 = ld_stream(spec + i1);
         const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
         float m0[4], m1[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            m0[s] = (WI_STREAM_LOADS ? ld_stream(mags.m[s] + j0) : mags.m[s][j0]) * h0; // target magnitude = mask x |X| (inference.cpp:175-183)
-            m1[s] = (WI_STREAM_LOADS ? ld_stream(mags.m[s] + j1) : mags.m[s][j1]) * h1;
+            m0[s] = ld_stream(mags.m[s] + j0) * h0; // target magnitude = mask x |X| (inference.cpp:175-183)
+            m1[s] = ld_stream(mags.m[s] + j1) * h1;
         }
         WienerBin wb;
         float4 rc[4];
@@ -135,11 +124,10 @@ __global__ __launch_bounds__(256 * NSRC) void wiener_istft_kernel(const float2 *
             const int s = src0 + sl;
             float2 o[2];
             if (WIENER)
-                wiener_bin_apply(wb, s, NSRC == 4 ? rc[sl] : sel4(s, rc), max_abs, o);
+                wiener_bin_apply(wb, s, rc[sl], max_abs, o);
             else
             {
-                const float ms0 = NSRC == 4 ? m0[sl] : (s == 0 ? m0[0] : s == 1 ? m0[1] : s == 2 ? m0[2] : m0[3]);
-                const float ms1 = NSRC == 4 ? m1[sl] : (s == 0 ? m1[0] : s == 1 ? m1[1] : s == 2 ? m1[2] : m1[3]);
+                const float ms0 = m0[sl], ms1 = m1[sl];
                 o[0] = make_float2(ms0 * p0.x, ms0 * p0.y);
                 o[1] = make_float2(ms1 * p1.x, ms1 * p1.y);
             }
