@@ -412,7 +412,9 @@ def main():
             lp = 2 if (not args.expanded_weights and not args.u8_dequant) else 6  # u8 W_hh: 1 fp16 plane x 2 fp16 planes of h
             groups = (B + 15) // 16  # the matrix instruction is 16 tracks wide: one MFMA phase per group of 16 lanes
             lstm_issued = rec * 16 * groups * lp * (1.25 if lp == 2 else 1.0)  # + the all-ones tile of the u8 form
-            lname = "lstm_batch_kernel" if groups == 1 else "lstm_batch2_kernel"
+            # 17 .. 32 lanes: two groups side by side (lstm_batchs_kernel) unless UMX_LSTM_GROUPED=0; 33 .. 48: the groups in turn
+            lname = "lstm_batch_kernel" if groups == 1 else \
+                "lstm_batchs_kernel" if groups == 2 and os.environ.get("UMX_LSTM_GROUPED") != "0" and H >= 512 else "lstm_batch2_kernel"
         else:
             lstm_issued = lstm_alg
             lname = "lstm_persistent_kernel" if lstm_mode >= 1 else "lstm_step_kernel"
@@ -439,7 +441,7 @@ def main():
                         "tracks_per_serial_step": B,
                         "note": "3*T serially dependent steps per segment, every step a chain-wide hand-off; frac_latency = measured cross-CU "
                                 "hand-off floor (tools/handoff_probe.hip) / step time",
-                        "traffic": find_traffic(("lstm_batch2" if B > 16 else "lstm_batch_kernel") if batched else "lstm_persistent")})
+                        "traffic": find_traffic(lname)})
 
         def stream_entry(key, name, nbytes, tneedle, per_lane_launches=False):
             # the streaming kernels of a track-batched context cover every lane in one launch (common.h LaneSet)

@@ -185,6 +185,9 @@ def test_hot_kernels_keep_their_register_budgets(device_asm):
     # batched recurrence, two groups: 12 waves per CU = at most 168
     vg, sp = find("lstm_batch2_kernelILi512ELi2ELb0E")
     assert vg <= 168 and sp == 0, (vg, sp)
+    # two groups of 16 lanes side by side, chains of 16 workgroups with two slices each (one workgroup per CU): nothing spilled
+    vg, sp = find("lstm_batchs_kernelILi512ELb0ELi2E")
+    assert vg <= 256 and sp == 0, (vg, sp)
     # fused Wiener / inverse STFT / overlap-add: 1024 threads = at most 128
     vg, sp = find("wiener_istft_kernelILb1EE")
     assert vg <= 128 and sp == 0, (vg, sp)

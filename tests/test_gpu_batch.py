@@ -143,6 +143,37 @@ def test_ping_pong_gemm_gives_the_bits_of_the_lock_step_kernel(pkg, tmp_path, mo
             assert (res[pp][1][b] == res["15"][1][b]).all(), (pp, b)
 
 
+def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, monkeypatch):
+    """17 .. 32 lanes, hidden 1024: csrc/lstm_batch.h's lstm_batchs_kernel (round 4: the two groups of 16 lanes side by side on the chip,
+    every chain 16 workgroups of two slices -- half the hand-off bytes per step) against csrc/lstm_batch2.h (the groups in turn through
+    256 twelve-wave workgroups; UMX_LSTM_GROUPED=0): per (unit, lane) the same matrix instructions in the same order and the same
+    summation tree, so stems and carried state agree bit for bit -- 20 and 32 lanes (a group with four lanes, two full groups), ragged
+    lengths, two segments, and the per-step driver of the new form."""
+    H, N = 1024, 40 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=53), H, compress=False)
+    for B in (20, 32):
+        waves = [[pkg.ggml.synth_audio(N - 97 * b, 2300 + 10 * b + s) for b in range(B)] for s in range(2)]
+        res = {}
+        for mode in ("0", None, "stepwise"):
+            if mode == "0":
+                monkeypatch.setenv("UMX_LSTM_GROUPED", "0")
+            else:
+                monkeypatch.delenv("UMX_LSTM_GROUPED", raising=False)
+            eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
+            flags = pkg.FLAG_LSTM_STEPWISE if mode == "stepwise" else 0
+            outs = [eng.infer_batch(w, flags) for w in waves]
+            res[mode] = (outs, [eng.track_stream_get(b) for b in range(B)])
+            eng.close()
+        for mode in (None, "stepwise"):
+            for s in range(2):
+                for b in range(B):
+                    for t in range(4):
+                        assert (res[mode][0][s][b][t] == res["0"][0][s][b][t]).all(), (B, mode, s, b, t)
+            for b in range(B):
+                assert (res[mode][1][b] == res["0"][1][b]).all(), (B, mode, b)
+
+
 def test_activation_planes_follow_the_data_range(pkg, po, tmp_path):
     """The plane GEMMs take every activation row as two fp16 planes of the row scaled by a power of two (csrc/gemm_planes.h):
     the scale follows the row, so a near-silent track (1e-5 of full scale, where a fixed-range fp16 split would be all

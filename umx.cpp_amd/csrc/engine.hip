@@ -321,6 +321,20 @@ template <int G> static const void *lstm_batch2_fn_g(int Hl, bool precise)
 // two or three groups of 16 lanes (lstm_batch2.h): u8-resident W_hh only
 static const void *lstm_batch2_fn(int Hl, int groups, bool precise) { return groups == 3 ? lstm_batch2_fn_g<3>(Hl, precise) : lstm_batch2_fn_g<2>(Hl, precise); }
 static int lstmb2_bulk(int groups) { return groups == 3 ? 2 : 4; } // ring rows per fetch: what fits the LDS beside the partial sums
+// two groups of 16 lanes side by side on the chip, chains of 16 workgroups with two slices each (lstm_batchs_kernel): hidden 512 / 1024,
+// u8-resident W_hh
+static const void *lstm_batchs_fn(int Hl, int groups, bool precise)
+{
+    if (groups != 2)
+        return nullptr;
+    switch (Hl)
+    {
+    case 256: return precise ? reinterpret_cast<const void *>(lstm_batchs_kernel<256, true, 2>) : reinterpret_cast<const void *>(lstm_batchs_kernel<256, false, 2>);
+    case 512: return precise ? reinterpret_cast<const void *>(lstm_batchs_kernel<512, true, 2>) : reinterpret_cast<const void *>(lstm_batchs_kernel<512, false, 2>);
+    default: return nullptr;
+    }
+}
+constexpr int kBatchsBulk = 1, kBatchsSpan = 2; // ring rows per fetch (LDS: 128 KB of partial sums + 2 rows x 16 lanes x 528 B), slices per workgroup
 static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
 {
     switch (Hl)
@@ -446,6 +460,7 @@ struct umx_hip_ctx
     // one segment of each of `nb` track lanes (lane i = track i of this context; audio[i] == nullptr: lane idle)
     int infer_batch(int nb, const float *const *audio_dev, const int *n, float *const *out /* [nb][4] */, unsigned flags);
     int lstm_batch_capacity = 0; // co-resident workgroups of the batched LSTM kernel
+    bool lstm_batchs_ok = false; // lstm_batchs_kernel (two groups of 16 lanes side by side, 16 workgroups per chain) fits the chip
     size_t state_floats() const { return (size_t)4 * 12 * Hl; }
     // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
     // whole track on the device (split_inference / shift_inference, umx.cpp:99-295)
@@ -1287,6 +1302,21 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                         UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTMB2_THREADS, l2));
                         per_cu = std::min(per_cu, v);
                     }
+                // ... or two groups side by side, each chain 16 workgroups of two slices: one workgroup per CU
+                lstm_batchs_ok = false;
+                if (lstm_batchs_fn(Hl, 2, false) && S % kBatchsSpan == 0)
+                {
+                    const size_t lg = lstmb_lds_bytes(LSTMB_GROUP_TRACKS, kBatchsBulk, kBatchsSpan);
+                    lstm_batchs_ok = true;
+                    for (int precise = 0; precise < 2; ++precise)
+                    {
+                        const void *fn = lstm_batchs_fn(Hl, 2, precise != 0);
+                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
+                        int v = 0;
+                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lg));
+                        lstm_batchs_ok = lstm_batchs_ok && v >= 1 && 2 * 8 * (S / kBatchsSpan) <= v * cus;
+                    }
+                }
             }
             lstm_batch_capacity = per_cu * cus;
         }
@@ -1525,11 +1555,18 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
             top = ln + 1;
     const int groups = (top + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS; // > 1: lstm_batch2.h, groups of 16 lanes in turn
     a.nbp = top > 8 ? 16 : top > 4 ? 8 : top > 2 ? 4 : top > 1 ? 2 : 1;
-    a.bulk = groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
-    const size_t lds = groups > 1 ? lstmb2_lds_bytes(groups, a.bulk) : lstmb_lds_bytes(a.nbp, a.bulk);
     const bool wq = whh_q[layer] != nullptr && !u8_dequant;
-    const void *fn = groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT) : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
-    const int threads = groups > 1 ? LSTMB2_THREADS : LSTM_THREADS;
+    // 17 .. 32 lanes: the two groups side by side on the chip (lstm_batchs_kernel: half the hand-off bytes) where it fits, else -- and
+    // for 33 .. 48 lanes -- the groups in turn through one twelve-wave workgroup (lstm_batch2.h).  Same bits either way.
+    const char *ge = getenv("UMX_LSTM_GROUPED"); // 0: always the groups in turn; read per launch: the tests switch it
+    const bool grouped = groups == 2 && lstm_batchs_ok && !(ge && atoi(ge) == 0);
+    a.bulk = grouped ? kBatchsBulk : groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
+    const size_t lds = grouped ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) : groups > 1 ? lstmb2_lds_bytes(groups, a.bulk) : lstmb_lds_bytes(a.nbp, a.bulk);
+    const void *fn = grouped      ? lstm_batchs_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
+                     : groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
+                                  : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
+    const int threads = groups > 1 && !grouped ? LSTMB2_THREADS : LSTM_THREADS;
+    const int Sw = grouped ? groups * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
     void *kargs[] = {&a};
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
     if (persistent)
@@ -1542,7 +1579,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         a.abort_at = ((last_flags & UMX_FLAG_DEBUG_LSTM_ABORT) && layer == 1) ? T / 2 : 0;
         UMX_HIP_CHECK(hipMemsetAsync(sl.lsync, 0, sizeof(unsigned) * (clear ? lsync_words : LSTM_SYNC_HEADER_WORDS), st));
         hipError_t e = lstm_gate_launch(device, st, 8 * S * 2, 2 * n_cus,
-                                        [&] { return hipLaunchKernel(fn, dim3(8 * S), dim3(threads), kargs, lds, st); });
+                                        [&] { return hipLaunchKernel(fn, dim3(8 * Sw), dim3(threads), kargs, lds, st); });
         if (e != hipSuccess)
         {
             (void)hipGetLastError();
@@ -1567,7 +1604,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
             a.t_end = step + 1;
             a.state = (step & 1) ? state_alt : state;
             a.state_out = (step & 1) ? state : state_alt;
-            UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * S), dim3(threads), kargs, lds, st));
+            UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * Sw), dim3(threads), kargs, lds, st));
         }
         if (T & 1) // the last launch wrote state_alt
             UMX_HIP_CHECK(hipMemcpy2DAsync(state + off, pitch, state_alt + off, pitch, row, (size_t)4 * B, hipMemcpyDeviceToDevice, st));
@@ -1707,6 +1744,11 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
     }
     a.rows_valid = nl * Tp;
     const dim3 grid(round_up(nl * Tp, 256) / 4, 1, nact);
+    if (which == SP_XS && a.cols <= 3072) // every target's operand comes from the same rows of x: read them once
+    {
+        hipLaunchKernelGGL(split_planes_shared_kernel<6>, dim3(grid.x), dim3(256), 0, st, a, nact);
+        return;
+    }
     if (a.cols <= 1024)
         hipLaunchKernelGGL(split_planes_kernel<2>, grid, dim3(256), 0, st, a);
     else if (a.cols <= 3072)

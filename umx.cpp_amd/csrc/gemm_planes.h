@@ -217,6 +217,87 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_kernel(S
     }
 }
 
+// The same for operands that ALL targets derive from ONE source row (fc1's input: x * input_scale + input_mean per target,
+// inference.cpp:78-83): the row is read once and the targets' planes are written one after the other -- round 3 launched the
+// kernel above per target and read the 1.07 GB of x four times per 32-lane step (7.7 GB of counter traffic, 1.52 ms).
+// grid (rows_out / 4), 256 threads = four rows; same arithmetic per target, same bits.
+template <int ITER> __global__ __launch_bounds__(256) void split_planes_shared_kernel(SplitArgs a, int ntargets)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int m = blockIdx.x * 4 + (tid >> 6);
+    const float *src = a.src[0] + (size_t)m * a.ld_src;
+    const bool live = m < a.rows_valid && m % a.Tp < a.T;
+    float x[ITER][8];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+    {
+        const int k = (it * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            x[it][j] = 0.f;
+        if (k < a.cols && live)
+        {
+            const float4 v0 = *reinterpret_cast<const float4 *>(src + k), v1 = *reinterpret_cast<const float4 *>(src + k + 4);
+            x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
+            x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
+        }
+    }
+    for (int tg = 0; tg < ntargets; ++tg)
+    {
+        unsigned short *dst = a.dst[tg] + (size_t)m * a.ld_dst + a.col0_dst;
+        const float *sc = a.scale[tg], *mn = a.mean[tg];
+        float xs[ITER][8];
+        float sum = 0.f, mx = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+        {
+            const int k = (it * 64 + lane) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xs[it][j] = 0.f;
+            if (k < a.cols && live)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    xs[it][j] = x[it][j] * sc[k + j] + mn[k + j];
+            sum += ((xs[it][0] + xs[it][1]) + (xs[it][2] + xs[it][3])) + ((xs[it][4] + xs[it][5]) + (xs[it][6] + xs[it][7]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                mx = fmaxf(mx, fabsf(xs[it][j]));
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            sum += __shfl_xor(sum, off, 64);
+            mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        }
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f)
+        {
+            int xe;
+            (void)frexpf(mx, &xe);
+            e = min(max(GP_SPLIT_FIXED_EXP + 1 - xe, -100), 100);
+        }
+        const float scale = ldexpf(1.0f, e), unscale = ldexpf(1.0f, -e);
+        if (lane == 0)
+        {
+            a.rowsum[tg][m] = sum;
+            a.rowunscale[tg][m] = unscale;
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+        {
+            const int k = (it * 64 + lane) * 8;
+            if (k < a.cols)
+            {
+                uint4 p1, p2;
+                split2_f16(xs[it], scale, p1, p2);
+                *reinterpret_cast<uint4 *>(dst + k) = p1;
+                *reinterpret_cast<uint4 *>(dst + a.plane + k) = p2;
+            }
+        }
+    }
+}
+
 // Wave tile 64 x 64 (MI = 2 matrix tiles of 32 rows along M): sixteen waves per 256 x 256 block, all in lock step on one
 // barrier per K tile.  The eight-wave 128 x 64 form of round 3 lives on as gemm_planes_pp.h, where the two waves of a SIMD take
 // turns at the matrix pipe: the default for every 256 x 256 launch (UMX_GEMM_PP=0 selects this kernel); it gives the bits of this

@@ -104,9 +104,9 @@ template <bool FAST> __device__ __forceinline__ void granule_store16(__amdgpu_bu
 // the only kernel of the profile with any); 16 bytes of padding spread them over all 64 banks.
 #define LSTMB_RING_PITCH_BYTES 272
 constexpr int LSTMB_RING_PITCH = LSTMB_RING_PITCH_BYTES;
-__host__ __device__ inline size_t lstmb_lds_bytes(int nbp, int bulk)
+__host__ __device__ inline size_t lstmb_lds_bytes(int nbp, int bulk, int sp = 1) // sp: slice span of the workgroup (lstmb_body)
 {
-    return (size_t)2 * 8 * 16 * nbp * 16 /* part */ + (size_t)2 * bulk * nbp * LSTMB_RING_PITCH /* ring */;
+    return (size_t)2 * 8 * 16 * sp * nbp * 16 /* part */ + (sp > 1 ? (size_t)0 : (size_t)2 * bulk * nbp * LSTMB_RING_PITCH) /* ring (sp = 1) */;
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
@@ -139,34 +139,42 @@ template <int NDW> __device__ __forceinline__ float2v tree_sum2(const float2v (&
 // the pair sums (h1 + h2) + (h1' + h2') travelling in the granules' free fourth dword, added by the consumer and folded over the
 // four 8-unit groups with two lane exchanges: 20 % fewer matrix-pipe cycles, 1.5 % SLOWER -- two dependent lane exchanges on the
 // turn's critical path cost more than four queued matrix instructions on an idle pipe.  Removed in round 4; the dword is zero.)
-template <int HL, bool WQ, bool FAST, bool PRECISE>
-__device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int slice, unsigned char *smem, int *abort_flag)
+// SP = slice span: the workgroup owns SP x 16 hidden units = SP x 64 gate columns (SP = 1: the form described above; SP = 2,
+// round 4: lstm_batchs_kernel below -- eight M tiles, every wave also a gate wave).  group: the workgroup serves lanes
+// [16 group, 16 group + 16) of the launch, with a granule area of their own.
+template <int HL, bool WQ, bool FAST, bool PRECISE, int SP = 1>
+__device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int slice, unsigned char *smem, int *abort_flag, int group = 0)
 {
+    const int lane0 = LSTMB_GROUP_TRACKS * group;
     constexpr int NKS = HL / 32;                 // K steps (32 hidden units each) of the whole contraction
     constexpr int KSW = NKS >= 8 ? NKS / 8 : 1;  // K steps per dot wave
     constexpr int NDW = NKS >= 8 ? 8 : NKS;      // waves that multiply (all 8 for Hl >= 256)
+    constexpr int MT = 4 * SP;                   // M tiles (16 gate columns = 4 hidden units each) of the workgroup
+    static_assert(SP == 1 || (SP == 2 && NKS >= 8 && WQ), "slice span 2: u8-resident W_hh, eight multiply waves");
     constexpr int NPL = WQ ? 1 : 3;              // bf16 planes of W_hh held in registers
     const int target = a.tmap[chain >> 1], dir = chain & 1, wchain = target * 2 + dir;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, q = l >> 4;
-    const int nbp = a.nbp, bulk = a.bulk, ring_mask = 2 * bulk - 1, T = a.T, S = a.S;
-    const unsigned lane_mask = a.lane_mask;
+    const int nbp = SP > 1 ? LSTMB_GROUP_TRACKS : a.nbp, bulk = a.bulk, ring_mask = 2 * bulk - 1, T = a.T, S = a.S;
+    const unsigned lane_mask = SP > 1 ? ((unsigned)(a.lane_mask >> lane0) & 0xffffu) : (unsigned)a.lane_mask;
     const bool lane_on = (lane_mask >> n) & 1u;
-    const bool dot_wave = w < NDW, gate_wave = w < 4; // gate wave w finishes M tile w (units 4w .. 4w+3 of the slice)
+    const bool dot_wave = w < NDW, gate_wave = w < MT; // gate wave w finishes M tile w (units 4w .. 4w+3 of the workgroup's)
+    constexpr int RING_PITCH = LSTMB_RING_PITCH;
 
-    float4 *part = reinterpret_cast<float4 *>(smem);                                   // [2][8 waves][4 tiles][4 q][nbp]
-    unsigned char *ring = smem + (size_t)2 * 8 * 16 * nbp * 16;                       // [2*bulk rows][nbp] blocks of 64 floats, LSTMB_RING_PITCH apart
+    float4 *part = reinterpret_cast<float4 *>(smem);                                   // [2][8 waves][MT tiles][4 q][nbp]
+    unsigned char *ring = smem + (size_t)2 * 8 * 4 * MT * nbp * 16;                   // [2*bulk rows][nbp] blocks of 64 SP floats, RING_PITCH apart
 
     // ---- W_hh fragments: lane (i = l & 15, q) of tile mt holds gate column 16 mt + i, units k = 32 ks' + 8 q + j
-    bf16x8 Wf[4][KSW][NPL];
+    bf16x8 Wf[MT][KSW][NPL];
     if (dot_wave)
     {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int ks = 0; ks < KSW; ++ks)
             {
                 float wv[8];
-                const size_t base = (((size_t)wchain * S + slice) * HL + (size_t)(w * KSW + ks) * 32 + 8 * q) * 64 + 16 * mt + n;
+                // the weights stay in slices of 64 gate columns ([chain][S][Hl][64]): tile mt is tile mt & 3 of slice SP slice + mt / 4
+                const size_t base = (((size_t)wchain * S + slice * SP + (mt >> 2)) * HL + (size_t)(w * KSW + ks) * 32 + 8 * q) * 64 + 16 * (mt & 3) + n;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     wv[j] = WQ ? (float)a.Wq[base + (size_t)j * 64] - 128.0f : whh_at(a.W, a.Wq, a.wsc[wchain], a.wof[wchain], base + (size_t)j * 64);
@@ -198,14 +206,14 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 wof2 = (a.wof[wchain] + 128.0f * a.wsc[wchain]) * (WQ ? 1.0f / HSCALE : 1.0f);
 
     // ---- per-(unit, track) cell state of the gate lanes, b_hh of the unit's four gates
-    const int unit = slice * 16 + 4 * (w & 3) + q;
-    const size_t st_h = (size_t)n * a.state_stride + state_off(target, a.layer, dir, 0, HL);
-    const size_t st_c = (size_t)n * a.state_stride + state_off(target, a.layer, dir, 1, HL);
+    const int unit = slice * 16 * SP + 4 * (w & (MT - 1)) + q;
+    const size_t st_h = (size_t)(lane0 + n) * a.state_stride + state_off(target, a.layer, dir, 0, HL);
+    const size_t st_c = (size_t)(lane0 + n) * a.state_stride + state_off(target, a.layer, dir, 1, HL);
     float c = 0.f, hlast = 0.f;
     float4 bh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gate_wave)
     {
-        bh = *reinterpret_cast<const float4 *>(a.bhh + ((size_t)wchain * S + slice) * 64 + 4 * (4 * w + q));
+        bh = *reinterpret_cast<const float4 *>(a.bhh + ((size_t)wchain * S + slice * SP + (w >> 2)) * 64 + 4 * (4 * (w & 3) + q));
         if (lane_on)
         {
             c = a.state[st_c + unit];
@@ -233,10 +241,10 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 
     // the polls are 16-byte L1-bypassing buffer loads (buffer_load_dwordx4 ... sc1): two granules each
     const __amdgpu_buffer_rsrc_t gran_rs =
-        __builtin_amdgcn_make_buffer_rsrc(a.sync + LSTM_SYNC_HEADER_WORDS, 0, (int)(lstmb_granule_words(HL) * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(a.sync + LSTM_SYNC_HEADER_WORDS + (size_t)group * lstmb_granule_words(HL), 0, (int)(lstmb_granule_words(HL) * 4), 0x00020000);
     gu32 *status = (gu32 *)a.status;
-    const float *const Pp = a.P[target] + ((size_t)dir * S + slice) * 64 + l;
-    float *const outp = a.out[target] + (size_t)n * a.out_stride + a.col0 + dir * HL + unit;
+    const float *const Pp = a.P[target] + (size_t)lane0 * a.p_stride + ((size_t)dir * S + slice * SP) * 64 + l;
+    float *const outp = a.out[target] + (size_t)(lane0 + n) * a.out_stride + a.col0 + dir * HL + unit;
     const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo, p_stride = a.p_stride;
     const unsigned tag_hi = a.tag_epoch << 12;
     const int t_begin = a.t_begin, t_end = a.t_end;
@@ -253,17 +261,27 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             const int r = first_row + i / nbp, nn = i % nbp;
             if (r < t_end && ((lane_mask >> nn) & 1u))
                 __builtin_amdgcn_global_load_lds((glb_ptr)(Pp + (size_t)nn * p_stride + (size_t)(dir == 0 ? r : T - 1 - r) * ldp),
-                                                 (lds_ptr)(size_t)(ring_lds + (unsigned)LSTMB_RING_PITCH * (unsigned)((r & ring_mask) * nbp + nn)), 4, 0, 0);
+                                                 (lds_ptr)(size_t)(ring_lds + (unsigned)RING_PITCH * (unsigned)((r & ring_mask) * nbp + nn)), 4, 0, 0);
         }
     };
-    if (dot_wave)
+    // SP > 1 (every wave multiplies AND finishes a tile): no ring -- a gate lane fetches the 16 bytes of its own (unit, track) of row
+    // step + 1 straight into registers right behind the polls of step `step`: a whole step ahead of its use, in front of the next
+    // step's polls in the memory queue (which return in order: the row is there when they are), no LDS and no other wave involved
+    const float *const Pg = a.P[target] + (size_t)(lane0 + n) * a.p_stride + ((size_t)dir * S + slice * SP + (w >> 2)) * 64 + 4 * (4 * (w & 3) + q);
+    float4 p4n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SP > 1)
+    {
+        if (gate_wave && lane_on && t_begin < t_end)
+            p4n = *reinterpret_cast<const float4 *>(Pg + (size_t)(dir == 0 ? t_begin : T - 1 - t_begin) * ldp);
+    }
+    else if (dot_wave)
     {
         fetch_rows(t_begin);
         fetch_rows(t_begin + bulk);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
     }
     __syncthreads(); // the first rows are read before the first step's barrier
-    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
+    const bool prof = a.prof != nullptr && group == 0 && chain == 0 && slice == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
     const int pw_idx = w == 0 ? 0 : 1;
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pc6 = 0, pc7 = 0;
     unsigned prof_spins = 0;
@@ -271,6 +289,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
     for (int step = t_begin; step < t_end; ++step)
     {
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        float4 p4s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (prof)
             c0 = clock64();
         if (a.abort_at && step == a.abort_at && tid == 0)
@@ -350,22 +369,28 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 // every gate wave of this workgroup is past iteration step - 2 (it has crossed the barrier of step - 1),
                 // so ring rows <= step - 2 may be replaced: rows [step-1+bulk, step-1+2 bulk) take the slots of
                 // [step-1-bulk, step-1); they are first read bulk - 1 barriers from now
-                if (step - t_begin > bulk && ((step - t_begin) & (bulk - 1)) == 1)
+                if (SP == 1 && step - t_begin > bulk && ((step - t_begin) & (bulk - 1)) == (bulk > 1 ? 1 : 0))
                     fetch_rows(step - 1 + bulk);
             }
             if (prof)
                 c1 = clock64();
-            floatx4 acc[4];
+            if (SP > 1)
+            {
+                p4s = p4n; // row `step`, requested a step ago
+                if (gate_wave && lane_on && step + 1 < t_end)
+                    p4n = *reinterpret_cast<const float4 *>(Pg + (size_t)(dir == 0 ? step + 1 : T - 2 - step) * ldp);
+            }
+            floatx4 acc[MT];
             floatx4 accH = {0.f, 0.f, 0.f, 0.f};
             const f16x8 ones16 = __builtin_bit_cast(f16x8, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
                 acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #define LSTMB_TERM(PW, PH)                                                                                         \
-    _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)            \
+    _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)           \
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[mt][ks][PW], hf[ks][PH], acc[mt], 0, 0, 0);
 #define LSTMB_TERM16(PH)                                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)            \
+    _Pragma("unroll") for (int ks = 0; ks < KSW; ++ks) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)           \
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, Wf[mt][ks][0]),                 \
                                                          __builtin_bit_cast(f16x8, hf[ks][PH]), acc[mt], 0, 0, 0);
             if (WQ)
@@ -393,12 +418,12 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             const float hsum_wave = WQ ? accH[0] : 0.f;
             if (n < nbp)
             {
-                float4 *pw = part + ((size_t)(((step & 1) * 8 + w) * 4) * 4 + q) * nbp + n;
+                float4 *pw = part + ((size_t)(((step & 1) * 8 + w) * MT) * 4 + q) * nbp + n;
                 // WQ: this k-range's share of W_hh h = wsc * sum (q-128) h + (wof + 128 wsc) * sum h (every row of accH
                 // holds the same sum of h)
                 const float hs = WQ ? wof2 * hsum_wave : 0.f;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     pw[(size_t)mt * 4 * nbp] = WQ ? make_float4(wsc * acc[mt][0] + hs, wsc * acc[mt][1] + hs, wsc * acc[mt][2] + hs, wsc * acc[mt][3] + hs)
                                                   : make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
             }
@@ -408,9 +433,9 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
         if (gate_wave && lane_on && step > t_begin)
             outp[(size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast; // lstm.cpp:163-164,170-171
         // W_ih x + b_ih of this lane's unit and track (in the ring since at least one barrier ago)
-        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gate_wave && n < nbp)
-            p4 = *reinterpret_cast<const float4 *>(ring + (size_t)((step & ring_mask) * nbp + n) * LSTMB_RING_PITCH + 16 * (4 * w + q));
+        float4 p4 = p4s;
+        if (SP == 1 && gate_wave && n < nbp)
+            p4 = *reinterpret_cast<const float4 *>(ring + (size_t)((step & ring_mask) * nbp + n) * RING_PITCH + 16 * (4 * w + q));
         if (prof)
             c2 = clock64();
         __syncthreads();
@@ -426,7 +451,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 #pragma unroll
             for (int ww = 0; ww < NDW; ++ww)
             {
-                const float4 v4 = part[((size_t)((((step & 1) * 8 + ww) * 4 + w) * 4) + q) * nbp + n];
+                const float4 v4 = part[((size_t)((((step & 1) * 8 + ww) * MT + w) * 4) + q) * nbp + n];
                 pa[ww] = float2v{v4.x, v4.y};
                 pb[ww] = float2v{v4.z, v4.w};
             }
@@ -539,6 +564,59 @@ template <int HL, bool WQ, bool PRECISE> __global__ __launch_bounds__(LSTM_THREA
         lstmb_body<HL, WQ, true, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3]);
     else
         lstmb_body<HL, WQ, false, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3]);
+}
+
+// ---- more than 16 track lanes (round 4): every GROUP of 16 lanes gets a part of the chip to itself.
+// What a step of the recurrence costs is the hand-off: every workgroup of a chain reads the whole h of its chain, for every lane it
+// serves -- 512 units x 16 lanes x 16-byte granules (8 bytes of payload) = 65.5 KB per group and step.  lstm_batch2.h runs the groups
+// of 16 lanes through all 256 workgroups IN TURN: 256 x 2 x 65.5 KB = 33.5 MB cross the L2s per step, ~10 TB/s at the measured 3.3 us --
+// more than half of what the L2 -> CU path delivers for this access width (tools/lds_probe: ~18 TB/s), so the polls' "round trip" is
+// mostly transfer time, and splitting the same work over independent four-wave workgroups (tried first this round: groups as
+// chains of their own, two workgroups per CU, the same bytes) ran the same 3.4 us.  Fewer readers is what cuts the bytes: here a
+// chain is 16 workgroups of SP = 2 slices (32 hidden units = 128 gate columns, eight M tiles; twice the matrix instructions and
+// registers per wave, every wave a gate wave), a group's eight chains take 128 CUs, and TWO groups sit side by side on the chip:
+// 256 x 65.5 KB = 16.8 MB per step for the same 32 lanes.  Arithmetic per (unit, lane): lstmb_body's, unchanged -- the bits of
+// lstm_batch_kernel.  Census: every XCD must receive G x S / SP workgroups (32 = one per CU); ticket / (S / SP) picks one of the
+// XCD's G chains, ticket % (S / SP) the slice; chains are numbered so that a (group, chain) pair lives on ONE XCD.
+template <int HL, bool PRECISE, int G> __global__ __launch_bounds__(LSTM_THREADS, 2) void lstm_batchs_kernel(LstmBArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lstmbs_smem[];
+    __shared__ int s_ctl[4]; // chain, slice (or ticket), fast, abort
+    constexpr int SP = 2;
+    const int tid = threadIdx.x, SW = a.S / SP; // workgroups per chain
+    if (tid == 0)
+    {
+        if (a.census)
+            lstm_census(a.sync, a.status, G * SW, (int)gridDim.x, a.force_safe, s_ctl);
+        else
+        {
+            s_ctl[2] = 0;
+            s_ctl[3] = 0;
+        }
+    }
+    __syncthreads();
+    if (s_ctl[3])
+        return;
+    int vc, slice; // virtual chain = group x 8 + chain
+    if (s_ctl[2])
+    {
+        vc = s_ctl[0] * G + s_ctl[1] / SW; // XCD x holds the virtual chains x G .. x G + G - 1
+        slice = s_ctl[1] % SW;
+    }
+    else // static roles: the grid is G x (chains of the launch) x S / SP; virtual chains in blocks of `nch` per group
+    {
+        const int nch = (int)gridDim.x / (G * SW), v = (int)blockIdx.x / SW;
+        vc = (v / nch) * 8 + v % nch;
+        slice = (int)blockIdx.x % SW;
+    }
+    const int group = vc >> 3, chain = vc & 7;
+    const unsigned gmask = (unsigned)(a.lane_mask >> (LSTMB_GROUP_TRACKS * group)) & 0xffffu;
+    if (chain >= a.nchains || gmask == 0u)
+        return;
+    if (s_ctl[2])
+        lstmb_body<HL, true, true, PRECISE, SP>(a, chain, slice, lstmbs_smem, &s_ctl[3], group);
+    else
+        lstmb_body<HL, true, false, PRECISE, SP>(a, chain, slice, lstmbs_smem, &s_ctl[3], group);
 }
 
 } // namespace umx

@@ -123,6 +123,12 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
     }
     __syncthreads(); // the first rows are read before the first barrier of the loop
 
+    // in-kernel profiler (UMX_FLAG_LSTM_PROFILE; bench.py --lstm-profile): wave 0 (a multiply wave) and wave 8 (a gate wave) of
+    // one workgroup count the shader cycles of a group's turn -- poll | fragments + matrix instructions + partial sums | barrier |
+    // gate phase -- summed over groups and steps
+    const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == 0 || w == 8);
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+
     for (int step = t_begin; step < t_end; ++step)
     {
         if (a.abort_at && step == a.abort_at && tid == 0)
@@ -133,6 +139,10 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
 #pragma unroll
         for (int g = 0; g < G; ++g)
         {
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            unsigned prof_spins = 0;
+            if (prof)
+                c0 = c1 = clock64();
             if (dot_wave)
             {
                 f16x8 hf[KSW][2];
@@ -192,6 +202,9 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                         }
                         __builtin_amdgcn_s_sleep(LSTMB_RETRY_SLEEP);
                     }
+                    prof_spins = spins;
+                    if (prof)
+                        c1 = clock64();
 #pragma unroll
                     for (int ks = 0; ks < KSW; ++ks)
                     {
@@ -235,9 +248,13 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
             float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gate_wave)
                 p4 = *reinterpret_cast<const float4 *>(ring + (size_t)((g * 2 * bulk + (step & ring_mask)) * NB + n) * LSTMB_RING_PITCH + 16 * (4 * gw + q));
+            if (prof)
+                c2 = clock64();
             __syncthreads();
             if (*abort_flag)
                 return;
+            if (prof)
+                c3 = clock64();
             if (gate_wave)
             {
                 float2v pa[8], pb[8];
@@ -286,7 +303,25 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                     }
                 }
             }
+            if (prof)
+            {
+                const long long c4 = clock64();
+                pc[0] += (unsigned long long)(c1 - c0);
+                pc[1] += (unsigned long long)(c2 - c1);
+                pc[2] += (unsigned long long)(c3 - c2);
+                pc[3] += (unsigned long long)(c4 - c3);
+                pc[4] += 1;
+                pc[5] += prof_spins;
+            }
         }
+    }
+    if (prof && l == 0)
+    {
+        const int pw_idx = w == 0 ? 0 : 1;
+        for (int i = 0; i < 6; ++i)
+            a.prof[(a.layer * 2 + pw_idx) * 8 + i] = (t_begin == 0 ? 0ull : a.prof[(a.layer * 2 + pw_idx) * 8 + i]) + pc[i];
+        a.prof[(a.layer * 2 + pw_idx) * 8 + 6] = 0;
+        a.prof[(a.layer * 2 + pw_idx) * 8 + 7] = 0;
     }
     if (gate_wave) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
 #pragma unroll

@@ -86,22 +86,61 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     int tl = tid;
     asm volatile("" : "+v"(tl));
     const int j = tl & 255;
+    // the streamed inputs (mixture, masks: HBM) of BOTH main bins of the thread are requested before the first is used -- round 3
+    // requested a bin's fourteen loads, waited for them, computed, and only then requested the next bin's: two memory latencies
+    // per frame with every wave of the workgroup in the same place.  (R is L2-resident and stays with its bin: 16 registers.)
+    constexpr int NQ = (NFFT / 2 + WI_THREADS) / WI_THREADS; // 3: bins tl, tl + 1024, and 2048 for thread 0
+    float2 Xq[2][2];
+    float mq[2][2][4];
 #pragma unroll
-    for (int q = 0; q < (NFFT / 2 + WI_THREADS) / WI_THREADS; ++q)
+    for (int q = 0; q < 2; ++q)
+    {
+        const int b = tl + WI_THREADS * q;
+        Xq[q][0] = ld_stream(spec + ((size_t)0 * T + f) * NBINS + b);
+        Xq[q][1] = ld_stream(spec + ((size_t)1 * T + f) * NBINS + b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            mq[q][0][s] = ld_stream(mags.m[s] + mask_index(0, T, f, b));
+            mq[q][1][s] = ld_stream(mags.m[s] + mask_index(1, T, f, b));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
     {
         const int b = tl + WI_THREADS * q;
         if (b > NFFT / 2)
             break;
-        const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
-        const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
-        const float2 X0 = ld_stream(spec + i0), X1 = ld_stream(spec + i1);
-        const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
+        float2 X0, X1;
         float m0[4], m1[4];
+        if (q < 2)
+        {
+            X0 = Xq[q < 2 ? q : 0][0];
+            X1 = Xq[q < 2 ? q : 0][1];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+            {
+                m0[s] = mq[q < 2 ? q : 0][0][s];
+                m1[s] = mq[q < 2 ? q : 0][1][s];
+            }
+        }
+        else
+        {
+            X0 = ld_stream(spec + ((size_t)0 * T + f) * NBINS + b);
+            X1 = ld_stream(spec + ((size_t)1 * T + f) * NBINS + b);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+            {
+                m0[s] = ld_stream(mags.m[s] + mask_index(0, T, f, b));
+                m1[s] = ld_stream(mags.m[s] + mask_index(1, T, f, b));
+            }
+        }
+        const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            m0[s] = ld_stream(mags.m[s] + j0) * h0; // target magnitude = mask x |X| (inference.cpp:175-183)
-            m1[s] = ld_stream(mags.m[s] + j1) * h1;
+            m0[s] *= h0; // target magnitude = mask x |X| (inference.cpp:175-183)
+            m1[s] *= h1;
         }
         WienerBin wb;
         float4 rc[4];
