@@ -266,7 +266,8 @@ int umx_hip_segment_finish_device(umx_hip_ctx *ctx, float *const out_dev[4]);
 int umx_hip_segment_discard(umx_hip_ctx *ctx); /* closes the phased segment where it stands (a rank that only contributes magnitudes) */
 /* Persistent LSTM launches of every context on `device` leave `cus` compute units out of their co-residency budget
  * (the admission gate of umx_hip_sync's comment): room for kernels that are not this engine's and that may sit on a CU
- * for a long time -- RCCL's send / recv kernels in host/mgpu.cpp.  Process-wide; 0 gives the budget back. */
+ * for a long time -- RCCL's send / recv kernels in host/mgpu.cpp.  Process-wide, per device: cus > 0 files a request (the largest
+ * outstanding one applies), -cus gives one request of that size back (UMX_ERR_ARG if there is none), 0 drops every request. */
 int umx_hip_gate_reserve(int device, int cus);
 void *umx_hip_phase_stream(umx_hip_ctx *ctx);
 float *umx_hip_stream_state_device(umx_hip_ctx *ctx);

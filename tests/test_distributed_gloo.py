@@ -127,3 +127,33 @@ def test_python_overlap_add_weights_equal_the_host_driver(pkg):
         ks = [k for k in list(range(0, n, max(1, n // 997))) + [n - 1, N // 2 - 1, N // 2] if 0 <= k < n]
         for k in ks:
             assert w[k] == np.float32(lib.umx_transition_weight(k, n, N)), (N, n, k)
+
+
+def test_survivor_of_a_dead_rank_returns_an_error(tmp_path):
+    """A rank that dies mid-track (host/split.cpp's carry schedule over gloo): the survivor's next receive fails, the transport
+    callback reports it, and umx_split_inference_carry returns an error code within the transport's timeout instead of hanging
+    (host/mgpu.cpp does the same for the device path: ncclCommAbort + return).  The ranks are started by hand: torchrun would
+    kill the survivor itself."""
+    import os
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = {**os.environ, "RANK": str(rank), "WORLD_SIZE": "2", "LOCAL_RANK": str(rank), "MASTER_ADDR": "127.0.0.1",
+               "MASTER_PORT": str(port), "OMP_NUM_THREADS": "1"}
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "kill_worker.py"), str(tmp_path)], env=env, cwd=str(ROOT),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        rcs = [p.wait(timeout=180) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs[1] == 7, (rcs, procs[1].stderr.read()[-2000:])  # rank 1 died where it was told to
+    assert rcs[0] == 0, (rcs, procs[0].stderr.read()[-2000:])
+    verdict, seconds = (tmp_path / "rank0.txt").read_text().splitlines()[:2]
+    assert verdict.startswith("error"), verdict  # not "completed", and not a hang (the wait above would have timed out)
+    assert float(seconds) < 120, seconds
+    assert not (tmp_path / "rank1.txt").exists()

@@ -200,7 +200,7 @@ class Engine:
         gemm: "planes" (fp16 matrix cores, operands pre-split into fp16 planes, LDS-DMA staging: the default with tracks > 1
         or lstm_batched) or "bf16x3" (bf16 terms, both operands split while every tile is staged: the default of the
         single-track engine); "f32" (the fp32-MFMA flavour of rounds 1-2) is refused;
-        tracks: independent track lanes (1..16) run together per call (infer_batch*);
+        tracks: independent track lanes (1..48) run together per call (infer_batch*);
         lstm_batched: use the batched (matrix-core) LSTM kernel also on a 1-track context."""
         self.lib = hip_lib()
         views, self._keep = views_from_file_tensors(targets, quantised)

@@ -215,6 +215,7 @@ struct LstmGate
     std::vector<hipEvent_t> pool;
     unsigned long long seq = 0;
     int reserved = 0; // half CUs kept free for kernels that are not this engine's (RCCL send / recv: umx_hip_gate_reserve)
+    std::vector<int> reservations; // outstanding requests in CUs: `reserved` follows the largest
 };
 LstmGate g_gate[16];
 
@@ -1136,6 +1137,20 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     // done by the time an LSTM grid retires, so that two grids would be resident all the time: 7.57 ms per segment against
     // 6.70 with two; the grids and the GEMM blocks beside them only slow each other down, avg LSTM launch 3.03 -> 3.79 ms.)
     nslots = 2;
+    if (gemm_planes)
+    {
+        // the plane GEMMs address their operands and fc3's mask output through buffer resources with 32-bit byte offsets
+        // (gemm_planes.h: both planes of an operand behind one base; gemm_common.h: all lanes' masks behind one base): refuse
+        // lane x segment-length combinations that do not fit instead of reading zeros past the range check
+        const unsigned long long rows = (unsigned long long)B * Tp + Mpad;
+        const unsigned long long planes_bytes = 2ull * rows * (unsigned long long)std::max(KX, 2 * H) * 2ull;
+        const unsigned long long mask_bytes = (unsigned long long)B * 2ull * T * MAGP * 4ull;
+        if (planes_bytes >= (1ull << 31) || mask_bytes >= (1ull << 32))
+        {
+            set_error("track lanes x segment length exceed the 32-bit addressing of the plane GEMMs' operands: fewer lanes or a shorter segment");
+            return UMX_ERR_ARG;
+        }
+    }
     for (int si = 0; si < nslots; ++si)
     {
         Slot &sl = slot[si];
@@ -2904,11 +2919,22 @@ float *umx_hip_target_mag_device(umx_hip_ctx *ctx, int target, size_t *floats)
 }
 int umx_hip_gate_reserve(int device, int cus)
 {
-    if (device < 0 || cus < 0)
+    if (device < 0)
         return UMX_ERR_ARG;
     LstmGate &g = g_gate[device & 15];
     std::lock_guard<std::mutex> lock(g.m);
-    g.reserved = 2 * cus;
+    if (cus > 0)
+        g.reservations.push_back(cus);
+    else if (cus < 0) // gives ONE request of that size back: another driver's request on the same device stays
+    {
+        auto it = std::find(g.reservations.begin(), g.reservations.end(), -cus);
+        if (it == g.reservations.end())
+            return UMX_ERR_ARG;
+        g.reservations.erase(it);
+    }
+    else
+        g.reservations.clear();
+    g.reserved = g.reservations.empty() ? 0 : 2 * *std::max_element(g.reservations.begin(), g.reservations.end());
     return UMX_OK;
 }
 
@@ -3000,6 +3026,13 @@ int umx_hip_order_before(umx_hip_ctx *ctx, void *hip_stream)
     for (int si = 0; si < ctx->nslots && e == hipSuccess; ++si)
     {
         e = hipEventRecord(ctx->order_ev, ctx->slot[si].stream);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent((hipStream_t)hip_stream, ctx->order_ev, 0);
+    }
+    // the host-pointer calls download their stems on a stream of their own: "everything queued so far" includes those copies
+    if (ctx->copy_stream && e == hipSuccess)
+    {
+        e = hipEventRecord(ctx->order_ev, ctx->copy_stream);
         if (e == hipSuccess)
             e = hipStreamWaitEvent((hipStream_t)hip_stream, ctx->order_ev, 0);
     }

@@ -119,7 +119,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmTarget &tg, const GemmAr
     const unsigned dA = ((unsigned)args.mag_lane - (unsigned)args.Tp_lane * MAGP) * 4u; // second lane: + lane stride, - Tp rows
     // fc3 only (dead code elsewhere): buffer resource of the mask output
     const int lanes = args.Tp_lane ? (args.lanes ? args.lanes : args.M / args.Tp_lane) : 1;
-    const int mag_bytes = MODE == G_FC3 ? (int)((args.Tp_lane ? (size_t)lanes * args.mag_lane : (size_t)2 * args.T * MAGP) * 4) : 0;
+    // (unsigned: 48 lanes x T = 2584 is 2.16e9 bytes; engine.hip refuses launches beyond 2^32)
+    const unsigned mag_bytes = MODE == G_FC3 ? (unsigned)((args.Tp_lane ? (size_t)lanes * args.mag_lane : (size_t)2 * args.T * MAGP) * 4) : 0u;
     const __amdgpu_buffer_rsrc_t rs_mag = __builtin_amdgcn_make_buffer_rsrc(tg.C, 0, mag_bytes, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)

@@ -46,6 +46,7 @@ struct umx_mgpu
     size_t arena_floats = 0;
     int *status_dev = nullptr;
     long long stats[5] = {0, 0, 0, 0, 0};
+    int reserve_device = 0, reserved_cus = 0; // umx_hip_gate_reserve request of this driver (given back by umx_mgpu_destroy)
 
     void abort_comms() // a rank that gives up must not leave kernels of its own spinning in RCCL
     {
@@ -128,9 +129,10 @@ static int create_impl(umx_mgpu *m, const char *id, char *err)
     // RCCL's kernels sit on compute units for as long as a transfer waits for its peer: keep them out of the budget
     // of the persistent LSTM grids (which need all their workgroups resident at once)
     const char *e = getenv("UMX_MGPU_RESERVE_CUS");
-    int dev = 0;
-    MG_HIP(hipGetDevice(&dev));
-    (void)umx_hip_gate_reserve(dev, e ? atoi(e) : 16);
+    MG_HIP(hipGetDevice(&m->reserve_device)); // the engine's device: this thread made it current to create the context
+    m->reserved_cus = std::max(0, e ? atoi(e) : 16);
+    if (m->reserved_cus > 0 && umx_hip_gate_reserve(m->reserve_device, m->reserved_cus) != UMX_OK)
+        m->reserved_cus = 0;
     return UMX_OK;
 }
 
@@ -187,9 +189,8 @@ extern "C" void umx_mgpu_destroy(umx_mgpu *m)
         (void)hipFree(m->arena);
     if (m->status_dev)
         (void)hipFree(m->status_dev);
-    int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess)
-        (void)umx_hip_gate_reserve(dev, 0);
+    if (m->reserved_cus > 0) // this driver's own request, on the device it was filed for -- other drivers' requests stay
+        (void)umx_hip_gate_reserve(m->reserve_device, -m->reserved_cus);
     delete m;
 }
 
