@@ -2,8 +2,10 @@
 // SIMD take turns at the matrix pipe.
 //
 // What gemm_planes_kernel's main loop loses (profiles/r03_gemm_pace_experiments.txt, GP_PROFILE): all waves leave the
-// K tile's barrier together, read their fragments together (the LDS port saturated, the matrix pipe idle), then queue
-// their matrix instructions together -- a trip takes ~2,950 cycles where its matrix instructions need 2,048.  Here the
+// K tile's barrier together, read their fragments together (the matrix pipe idle meanwhile), then queue their matrix
+// instructions together -- a trip takes ~2,950 cycles where its matrix instructions need 2,048.  (The LDS port itself is not
+// the limit: 256 B/clk/CU for exactly these reads, tools/lds_probe.hip, of which a trip's reads + DMA writes take 40 %; what
+// is, is the L2 -> LDS path and the epilogue: DESIGN 4.6, "Round 4: one diagnosis".)  Here the
 // waves are two groups of four (one wave of each group per SIMD: waves are dealt to the SIMDs round-robin), half a
 // trip apart:
 //
