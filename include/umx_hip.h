@@ -118,10 +118,11 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
  * UMX_LSTM=batched, on a 1-track context) selects the batched kernel for every call, so a track's result never
  * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
  * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise.
- * More than 16 lanes (up to UMX_MAX_TRACKS): one workgroup serves groups of 16 lanes in turn (csrc/lstm_batch2.h), the
- * same bits per track; needs the u8-resident W_hh of a quantised model. */
+ * More than 16 lanes (up to UMX_MAX_TRACKS): 17 .. 32 lanes run as two groups of 16 side by side on the chip (csrc/lstm_batch.h,
+ * lstm_batchs_kernel: half the hand-off bytes per step; the best operating point per track), 33 .. 48 as groups of 16 in turn
+ * through one workgroup (csrc/lstm_batch2.h); the same bits per track either way; needs the u8-resident W_hh of a quantised model. */
 #define UMX_CREATE_LSTM_BATCHED 0x10u
-#define UMX_MAX_TRACKS 48 /* more than 16 need a quantised model with its u8 W_hh resident (groups of 16 lanes, csrc/lstm_batch2.h) */
+#define UMX_MAX_TRACKS 48 /* more than 16 need a quantised model with its u8 W_hh resident (groups of 16 lanes: csrc/lstm_batch.h, lstm_batch2.h) */
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                           const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
 int umx_hip_n_tracks(const umx_hip_ctx *ctx);
