@@ -175,6 +175,7 @@ struct Slot
     hipStream_t stream = nullptr;
     Lane lane[LSTMB_MAX_TRACKS];
     float *hbuf = nullptr;
+    bool lstm_wrote_planes[3] = {false, false, false}; // this call's recurrence of layer l wrote the next GEMM's A planes (run_lstm_layer_batched)
     unsigned *status = nullptr, *lsync = nullptr;
     unsigned long long *lprof = nullptr;
     hipEvent_t ev[ST_COUNT + 1] = {};
@@ -321,6 +322,9 @@ template <int G> static const void *lstm_batch2_fn_g(int Hl, bool precise)
 }
 // two or three groups of 16 lanes (lstm_batch2.h): u8-resident W_hh only
 static const void *lstm_batch2_fn(int Hl, int groups, bool precise) { return groups == 3 ? lstm_batch2_fn_g<3>(Hl, precise) : lstm_batch2_fn_g<2>(Hl, precise); }
+#ifndef UMX_FUSE_LSTM_PLANES
+#define UMX_FUSE_LSTM_PLANES 1
+#endif
 static int lstmb2_bulk(int groups) { return groups == 3 ? 2 : 4; } // ring rows per fetch: what fits the LDS beside the partial sums
 // two groups of 16 lanes side by side on the chip, chains of 16 workgroups with two slices each (lstm_batchs_kernel): hidden 512 / 1024,
 // u8-resident W_hh
@@ -462,6 +466,8 @@ struct umx_hip_ctx
     int infer_batch(int nb, const float *const *audio_dev, const int *n, float *const *out /* [nb][4] */, unsigned flags);
     int lstm_batch_capacity = 0; // co-resident workgroups of the batched LSTM kernel
     bool lstm_batchs_ok = false; // lstm_batchs_kernel (two groups of 16 lanes side by side, 16 workgroups per chain) fits the chip
+    bool lstm_rowsums = false;       // the batched recurrence hands the consuming plane GEMM the row sums of its output (lstm_batch.h, LstmBArgs::rs_dir)
+    bool lstm_writes_planes = false; // ... and writes that GEMM's A planes itself (contexts of up to 32 lanes: lstm_batch_kernel / lstm_batchs_kernel)
     size_t state_floats() const { return (size_t)4 * 12 * Hl; }
     // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
     // whole track on the device (split_inference / shift_inference, umx.cpp:99-295)
@@ -1186,8 +1192,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 for (unsigned short **q : {&la_p, &lb_p, &a2_p})
                     if (int rc = dalloc(q, 2 * ((size_t)B * Tp + Mpad) * H))
                         return rc;
-                for (int k = 0; k < 8; ++k)
-                    if (int rc = dalloc(&rs[k], (size_t)B * Tp + Mpad))
+                for (int k = 0; k < 8; ++k) // [2..4]: the recurrence's outputs, one array per direction when it writes the planes itself
+                    if (int rc = dalloc(&rs[k], ((size_t)B * Tp + Mpad) * (k >= 2 && k <= 4 ? 2 : 1)))
                         return rc;
             }
             for (int ln = 0; ln < B; ++ln)
@@ -1334,6 +1340,13 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 }
             }
             lstm_batch_capacity = per_cu * cus;
+            // the recurrence writes the plane GEMMs' A operands (layers 1, 2 and fc2's right half) and their row sums itself where
+            // it runs on the u8-resident W_hh (its gate lanes hold h as two fp16 planes, its all-ones tile the row sums): no
+            // split_planes launches for them (lstm_batch.h, LstmBArgs::planes).  -DUMX_FUSE_LSTM_PLANES=0: A/B builds
+            // More than 32 lanes (lstm_batch2.h, no register left): only the row sums; split_planes_kernel still writes the planes -- the
+            // same bits, so a track's result does not depend on the size of the context.
+            lstm_rowsums = UMX_FUSE_LSTM_PLANES && gemm_planes && !u8_dequant && whh_q[0] && whh_q[1] && whh_q[2];
+            lstm_writes_planes = lstm_rowsums && B <= 2 * LSTMB_GROUP_TRACKS;
         }
     }
     // dynamic LDS > 64 KiB must be opted into
@@ -1564,6 +1577,22 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     }
     a.nchains = 2 * nact;
     a.lane_mask = lane_mask;
+    const bool wq_layer = whh_q[layer] != nullptr && !u8_dequant;
+    const bool fuse = lstm_rowsums && wq_layer;
+    if (fuse)
+    {
+        const size_t rows_all = (size_t)B * Tp + Mpad;
+        for (int i = 0; i < 4; ++i)
+        {
+            const TargetAct &b = sl.lane[0].ta[i];
+            a.planes[i] = layer == 0 ? b.la_p : layer == 1 ? b.lb_p : b.cat_p; // (dropped below if the launch's kernel cannot write them)
+            a.rs_dir[i] = layer == 0 ? b.rs_la : layer == 1 ? b.rs_lb : b.rs_catR;
+        }
+        a.ldpl = a.ldo;
+        a.plane_elems = rows_all * (size_t)a.ldo;
+        a.rs_rows = rows_all;
+    }
+    a.Tp = Tp;
     int top = 0;
     for (int ln = 0; ln < LSTMB_MAX_TRACKS; ++ln)
         if ((lane_mask >> ln) & 1ull)
@@ -1582,6 +1611,13 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
                                   : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
     const int threads = groups > 1 && !grouped ? LSTMB2_THREADS : LSTM_THREADS;
     const int Sw = grouped ? groups * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
+    // the twelve-wave kernel of lstm_batch2.h takes the row sums but leaves the planes to split_planes_kernel
+    const bool writes_planes = fuse && lstm_writes_planes && (groups == 1 || grouped);
+    if (!writes_planes)
+        for (int i = 0; i < 4; ++i)
+            a.planes[i] = nullptr;
+    a.write_f32 = (last_flags & UMX_FLAG_DEBUG_TAPS) ? 1 : 0;
+    sl.lstm_wrote_planes[layer] = writes_planes;
     void *kargs[] = {&a};
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
     if (persistent)
@@ -1624,6 +1660,8 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         if (T & 1) // the last launch wrote state_alt
             UMX_HIP_CHECK(hipMemcpy2DAsync(state + off, pitch, state_alt + off, pitch, row, (size_t)4 * B, hipMemcpyDeviceToDevice, st));
     }
+    if (fuse) // the one row per direction that no later step multiplied with
+        hipLaunchKernelGGL(lstm_last_row_sum_kernel, dim3(top, 2 * nact), dim3(64), 0, st, a, nact);
     sl.last_persistent = persistent;
     UMX_HIP_CHECK(hipGetLastError());
     return UMX_OK;
@@ -1740,15 +1778,15 @@ void umx_hip_ctx::launch_split(Lane &ln, int nl, hipStream_t st, int which, cons
             a.cols = H; a.ld_src = 2 * H; a.ld_dst = 2 * H; a.col0_dst = 0; a.plane = rows_all * 2 * H;
             break;
         case SP_CATR: // last LSTM layer's output = right half
-            a.src[i] = c.cat + H; a.dst[i] = c.cat_p; a.rowsum[i] = c.rs_catR;
+            a.src[i] = c.cat + H; a.dst[i] = c.cat_p; a.rowsum[i] = lstm_rowsums ? nullptr : c.rs_catR;
             a.cols = H; a.ld_src = 2 * H; a.ld_dst = 2 * H; a.col0_dst = H; a.plane = rows_all * 2 * H;
             break;
         case SP_LA:
-            a.src[i] = c.la; a.dst[i] = c.la_p; a.rowsum[i] = c.rs_la;
+            a.src[i] = c.la; a.dst[i] = c.la_p; a.rowsum[i] = lstm_rowsums ? nullptr : c.rs_la;
             a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
             break;
         case SP_LB:
-            a.src[i] = c.lb; a.dst[i] = c.lb_p; a.rowsum[i] = c.rs_lb;
+            a.src[i] = c.lb; a.dst[i] = c.lb_p; a.rowsum[i] = lstm_rowsums ? nullptr : c.rs_lb;
             a.cols = H; a.ld_src = H; a.ld_dst = H; a.col0_dst = 0; a.plane = rows_all * H;
             break;
         default:
@@ -1803,6 +1841,8 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
             pm = &b.ih_p[layer];
             t.A = layer == 0 ? c.cat_p : layer == 1 ? c.la_p : c.lb_p;
             t.rs0 = layer == 0 ? c.rs_catL : layer == 1 ? c.rs_la : c.rs_lb;
+            if (layer > 0 && lstm_rowsums) // one row-sum array per direction, from the recurrence itself
+                t.rs1 = t.rs0 + rows_all;
             t.C = c.P; t.e0 = b.ih_b[layer];
             t.bsplit = 2 * H; // W_ih rows >= 4*Hl belong to the reverse direction's tensor
             g.N = 4 * H; g.K = H; g.lda = layer == 0 ? 2 * H : H; g.ldc = 4 * H;
@@ -1811,6 +1851,8 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
         case G_FC2:
             pm = &b.fc2_p;
             t.A = c.cat_p; t.C = c.a2; t.rs0 = c.rs_catL; t.rs1 = c.rs_catR;
+            if (lstm_rowsums)
+                t.rs2 = c.rs_catR + rows_all;
             t.e0 = b.bn2[0]; t.e1 = b.bn2[1]; t.e2 = b.bn2[2]; t.e3 = b.bn2[3];
             g.N = H; g.K = 2 * H; g.lda = 2 * H; g.ldc = H; g.a_plane = rows_all * 2 * H;
             break;
@@ -1874,8 +1916,10 @@ void umx_hip_ctx::launch_gemm_lanes(Slot &sl, hipStream_t st, int nb, const floa
         {
             // the A operand is split here, right before its consumer (every producer -- STFT, fc1, the LSTM layers,
             // fc2 -- writes fp32)
-            launch_split(sl.lane[l0], l1 - l0, st, mode == G_FC1 ? SP_XS : mode == G_IH ? (layer == 0 ? SP_CATL : layer == 1 ? SP_LA : SP_LB)
-                                                                   : mode == G_FC2 ? SP_CATR : SP_A2, active, nact);
+            const int which = mode == G_FC1 ? SP_XS : mode == G_IH ? (layer == 0 ? SP_CATL : layer == 1 ? SP_LA : SP_LB) : mode == G_FC2 ? SP_CATR : SP_A2;
+            const int from_layer = which == SP_LA ? 0 : which == SP_LB ? 1 : which == SP_CATR ? 2 : -1;
+            if (from_layer < 0 || !sl.lstm_wrote_planes[from_layer]) // else: written by the recurrence
+                launch_split(sl.lane[l0], l1 - l0, st, which, active, nact);
             launch_gemm_planes(sl.lane[l0], l1 - l0, st, mode, layer, active, nact, dbg);
         }
         else

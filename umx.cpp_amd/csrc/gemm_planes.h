@@ -41,7 +41,8 @@ struct GemmPTarget
     const unsigned short *B; // planes [NBP][N][K]; plane p at B + p * N * K
     float *C;
     const float *e0, *e1, *e2, *e3, *q0, *q1; // as GemmTarget
-    const float *rs0, *rs1; // row sums of A (rs1 optional: second half of a concatenated A)
+    const float *rs0, *rs1, *rs2; // row sums of A (rs1, rs2 optional: further parts of a concatenated A -- the skip concat's halves, the two
+                                  // directions of a recurrence that wrote its planes itself, lstm_batch.h); added as (rs0 + rs1) + rs2
     const float *rsc;       // per-row inverse scale of A (nullptr: GemmPArgs::a_unscale for every row)
     float bs[2], bo2[2];    // scale, offset + c * scale of the weight tensor(s); columns >= bsplit use [1]
     int bsplit;
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
         {
             const int m = m0 + i;
             fx[i] = bsc * (tg.rsc ? tg.rsc[m] : args.a_unscale); // a power of two times s: exact scaling
-            fx[BM + i] = o2 * (tg.rs1 ? tg.rs0[m] + tg.rs1[m] : tg.rs0[m]);
+            fx[BM + i] = o2 * (tg.rs2 ? (tg.rs0[m] + tg.rs1[m]) + tg.rs2[m] : tg.rs1 ? tg.rs0[m] + tg.rs1[m] : tg.rs0[m]);
         }
         __syncthreads();
 #pragma unroll

@@ -233,7 +233,7 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         {
             const int m = m0 + i;
             fx[i] = bsc * (tg.rsc ? tg.rsc[m] : args.a_unscale);
-            fx[BM + i] = o2 * (tg.rs1 ? tg.rs0[m] + tg.rs1[m] : tg.rs0[m]);
+            fx[BM + i] = o2 * (tg.rs2 ? (tg.rs0[m] + tg.rs1[m]) + tg.rs2[m] : tg.rs1 ? tg.rs0[m] + tg.rs1[m] : tg.rs0[m]);
         }
         __syncthreads();
 #pragma unroll

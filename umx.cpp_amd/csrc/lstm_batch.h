@@ -80,6 +80,16 @@ struct LstmBArgs
     int t_begin, t_end; // steps of this launch
     int abort_at;       // testing: every workgroup gives up at this step as if a poll had timed out (0 = never)
     int census;         // 1: take the census (t_end - t_begin > 1: needs the grid co-resident); 0: static roles
+    // Round 4: the recurrence writes the NEXT GEMM's A operand itself (u8-resident W_hh only).  The gate lanes hold h as the two
+    // fp16 planes of h * 2^14 anyway (the granule's payload = exactly what split_planes_kernel would produce from the fp32 row), and
+    // sum_k h'_k over a chain's 512 units -- the row sum the consumer's affine fix-up needs -- is what the all-ones matrix tile of
+    // every workgroup computes one step later.  planes[i] = nullptr: not fused (the fp32 rows are split by split_planes_kernel).
+    unsigned short *planes[4]; // target i: [2][rows][ldpl] fp16 bits; row = lane * Tp + frame, column = col0 + dir * Hl + unit
+    size_t plane_elems;        // elements between the two planes
+    float *rs_dir[4];          // target i: [2 dirs][rs_rows] row sums of this layer's output per direction (sum_k a_k, unscaled)
+    size_t rs_rows;
+    int ldpl, Tp;
+    int write_f32;             // with planes: also keep the fp32 rows of every step (debug taps); without planes they always are
 };
 
 __host__ __device__ inline size_t lstmb_granule_words(int Hl) { return (size_t)2 * 8 * Hl * 16 * 2; } // 32-bit words
@@ -104,9 +114,11 @@ template <bool FAST> __device__ __forceinline__ void granule_store16(__amdgpu_bu
 // the only kernel of the profile with any); 16 bytes of padding spread them over all 64 banks.
 #define LSTMB_RING_PITCH_BYTES 272
 constexpr int LSTMB_RING_PITCH = LSTMB_RING_PITCH_BYTES;
+constexpr size_t LSTMB_HSW_BYTES = 2 * 8 * 16 * sizeof(float); // sum_k h'_k per k-range and lane, two steps (fused row sums): the last KiB
 __host__ __device__ inline size_t lstmb_lds_bytes(int nbp, int bulk, int sp = 1) // sp: slice span of the workgroup (lstmb_body)
 {
-    return (size_t)2 * 8 * 16 * sp * nbp * 16 /* part */ + (sp > 1 ? (size_t)0 : (size_t)2 * bulk * nbp * LSTMB_RING_PITCH) /* ring (sp = 1) */;
+    return (size_t)2 * 8 * 16 * sp * nbp * 16 /* part */ + (sp > 1 ? (size_t)0 : (size_t)2 * bulk * nbp * LSTMB_RING_PITCH) /* ring (sp = 1) */ +
+           LSTMB_HSW_BYTES;
 }
 
 __device__ __forceinline__ bf16x8 as_bf16x8(const uint4 &v) { return __builtin_bit_cast(bf16x8, v); }
@@ -248,6 +260,27 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
     const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo, p_stride = a.p_stride;
     const unsigned tag_hi = a.tag_epoch << 12;
     const int t_begin = a.t_begin, t_end = a.t_end;
+    // fused A planes of the consumer (LstmBArgs::planes): this lane's column of its track lane's rows; row sums by workgroup 0 of a chain
+    unsigned short *const plp = (WQ && a.planes[target]) ? a.planes[target] + (size_t)(lane0 + n) * a.Tp * a.ldpl + a.col0 + dir * HL + unit : nullptr;
+    const size_t plane_elems = a.plane_elems, ldpl = (size_t)a.ldpl;
+    float *const rsp = (WQ && a.rs_dir[target] && slice == 0) ? a.rs_dir[target] + (size_t)dir * a.rs_rows + (size_t)lane0 * a.Tp : nullptr;
+    float *const hsw = reinterpret_cast<float *>(smem + lstmb_lds_bytes(nbp, bulk, SP) - LSTMB_HSW_BYTES); // [2][8 waves][16]: sum_k h'_k per k-range and lane
+    unsigned plast = 0; // the fp16 planes of hlast (h1 | h2 << 16)
+    // the row sum of the row that step `sm` multiplied with (h'_{sm-1}: frame sm - 1 forward, T - sm backward; at step 0 that is the
+    // carried state, not a row): the eight k-ranges' sums in a fixed tree, by sixteen lanes of the last multiply wave of the chain's
+    // workgroup 0 -- WHILE that wave waits for the next step's polls (or behind the loop), not on the hand-off's path: as a tail of
+    // the gate phase it made workgroup 0 the slowest producer of its chain and cost 6 % (19 % with the groups in turn).  The row of
+    // the launch's last step has no later step: lstm_last_row_sum_kernel.
+    auto row_sum_of_step = [&](int sm) {
+        if (rsp && w == NDW - 1 && l < nbp && sm > 0 && ((lane_mask >> l) & 1u))
+        {
+            float hp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < NDW; ++ww)
+                hp[ww] = hsw[((sm & 1) * 8 + ww) * 16 + l];
+            rsp[(size_t)l * a.Tp + (size_t)(dir == 0 ? sm - 1 : T - sm)] = tree_sum<NDW>(hp) * (1.0f / 16384.0f);
+        }
+    };
 
     // W_ih x + b_ih rows: bulk fetch into the LDS ring (see lstm_kernels.h for why), rows x active lanes dealt to the
     // dot waves; a wave-instruction moves the 64 columns of one (row, track)
@@ -329,6 +362,8 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 #pragma unroll
                             for (int i = 0; i < 4; ++i)
                                 v[ks][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gran_rs, goff[ks] + i * 64 * nbp, 0, 16)); // sc1
+                        if (spins == 0)
+                            row_sum_of_step(step - 1); // (LDS reads and one store in the shadow of the loads just issued)
                         unsigned bad = 0;
 #pragma unroll
                         for (int ks = 0; ks < KSW; ++ks)
@@ -416,6 +451,8 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
 #undef LSTMB_TERM
 #undef LSTMB_TERM16
             const float hsum_wave = WQ ? accH[0] : 0.f;
+            if (rsp && q == 0) // sum over this wave's k-range of h'_{step-1} for lane n: every workgroup has it, workgroup 0 of the chain keeps it
+                hsw[((step & 1) * 8 + w) * 16 + n] = hsum_wave;
             if (n < nbp)
             {
                 float4 *pw = part + ((size_t)(((step & 1) * 8 + w) * MT) * 4 + q) * nbp + n;
@@ -431,7 +468,18 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
         // the output row of the PREVIOUS step goes out here, behind the polls: vector memory operations complete in
         // order, and a store queued in front of the poll loads would sit on the hand-off's critical path
         if (gate_wave && lane_on && step > t_begin)
-            outp[(size_t)(dir == 0 ? step - 1 : T - step) * ldo] = hlast; // lstm.cpp:163-164,170-171
+        {
+            const size_t fr = (size_t)(dir == 0 ? step - 1 : T - step);
+            // (every store instruction of the step costs: with the planes the fp32 row is written only for the debug taps -- measured at
+            // 32 lanes, per launch: one store 6.40 ms, two 6.56, three 6.85; the LAST row of a launch is always written, below)
+            if (!plp || a.write_f32)
+                outp[fr * ldo] = hlast; // lstm.cpp:163-164,170-171
+            if (plp)
+            {
+                plp[fr * ldpl] = (unsigned short)(plast & 0xffffu);
+                plp[plane_elems + fr * ldpl] = (unsigned short)(plast >> 16);
+            }
+        }
         // W_ih x + b_ih of this lane's unit and track (in the ring since at least one barrier ago)
         float4 p4 = p4s;
         if (SP == 1 && gate_wave && n < nbp)
@@ -502,6 +550,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             {
                 c = c_t;
                 hlast = h;
+                plast = mine12;
                 if ((q & 1) == 0) // publish the pair (this unit, the next), tagged step + 1
                 {
                     const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u),
@@ -522,10 +571,20 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
             pc[5] += prof_spins;
         }
     }
+    if (t_end > t_begin)
+        row_sum_of_step(t_end - 1);
     if (gate_wave && lane_on) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
     {
         if (t_end > t_begin)
-            outp[(size_t)(dir == 0 ? t_end - 1 : T - t_end) * ldo] = hlast;
+        {
+            const size_t fr = (size_t)(dir == 0 ? t_end - 1 : T - t_end);
+            outp[fr * ldo] = hlast;
+            if (plp)
+            {
+                plp[fr * ldpl] = (unsigned short)(plast & 0xffffu);
+                plp[plane_elems + fr * ldpl] = (unsigned short)(plast >> 16);
+            }
+        }
         a.state_out[st_h + unit] = hlast;
         a.state_out[st_c + unit] = c;
     }
@@ -617,6 +676,32 @@ template <int HL, bool PRECISE, int G> __global__ __launch_bounds__(LSTM_THREADS
         lstmb_body<HL, true, true, PRECISE, SP>(a, chain, slice, lstmbs_smem, &s_ctl[3], group);
     else
         lstmb_body<HL, true, false, PRECISE, SP>(a, chain, slice, lstmbs_smem, &s_ctl[3], group);
+}
+
+// The row sums of the ONE row per direction that no later step multiplies with (the launch's last step: frame T - 1 of the forward
+// chain, frame 0 of the backward chain): sum_k of the two fp16 planes of h_k * 2^14 -- formed here from the fp32 row exactly as the
+// gate lanes / split_planes_kernel form them, so it does not matter who wrote the planes -- in a fixed tree over the lanes.  (The
+// order of lstmb_body's all-ones tile is the matrix pipe's own; this row has its own fixed one, and every path runs this kernel for
+// this row: a track's bits do not depend on the path.)  grid (lanes, targets x 2 dirs), 64 threads.
+__global__ __launch_bounds__(64) void lstm_last_row_sum_kernel(LstmBArgs a, int ntargets)
+{
+    const int ln = blockIdx.x, target = a.tmap[blockIdx.y >> 1], dir = blockIdx.y & 1, l = threadIdx.x, HL = a.Hl;
+    if (!((a.lane_mask >> ln) & 1ull) || (int)(blockIdx.y >> 1) >= ntargets || !a.rs_dir[target])
+        return;
+    const size_t fr = dir == 0 ? (size_t)a.T - 1 : 0, row = (size_t)ln * a.Tp + fr;
+    const float *h = a.out[target] + (size_t)ln * a.out_stride + fr * a.ldo + a.col0 + dir * HL;
+    float s = 0.f;
+    for (int k = l; k < HL; k += 64) // lane l: units l, l + 64, ...; then the 64 lanes by xor-exchange
+    {
+        const float hs14 = h[k] * 16384.0f;
+        const _Float16 h1 = (_Float16)hs14, h2 = (_Float16)(hs14 - (float)h1);
+        s += (float)h1 + (float)h2;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        s += __shfl_xor(s, off, 64);
+    if (l == 0)
+        a.rs_dir[target][(size_t)dir * a.rs_rows + row] = s * (1.0f / 16384.0f);
 }
 
 } // namespace umx

@@ -34,7 +34,8 @@ namespace umx
 constexpr int LSTMB2_THREADS = 768;
 __host__ __device__ inline size_t lstmb2_lds_bytes(int groups, int bulk)
 {
-    return (size_t)groups * 8 * 16 * 16 * 16 /* part */ + (size_t)groups * 2 * bulk * 16 * LSTMB_RING_PITCH /* rings */;
+    return (size_t)groups * 8 * 16 * 16 * 16 /* part */ + (size_t)groups * 2 * bulk * 16 * LSTMB_RING_PITCH /* rings */ +
+           (size_t)2 * groups * 8 * 16 * sizeof(float) /* sum_k h'_k per step parity, group, k-range and lane (fused row sums, lstm_batch.h) */;
 }
 
 template <int HL, int G, bool FAST, bool PRECISE>
@@ -50,6 +51,7 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
 
     float4 *part = reinterpret_cast<float4 *>(smem);                                // [G][8 waves][4 tiles][4 q][16]
     unsigned char *ring = smem + (size_t)G * 8 * 16 * NB * 16;                      // [G][2*bulk rows][16] blocks of 64 floats, LSTMB_RING_PITCH apart
+    float *const hsw = reinterpret_cast<float *>(smem + lstmb2_lds_bytes(G, a.bulk) - (size_t)2 * G * 8 * 16 * sizeof(float)); // [2][G][8 waves][16]
 
     // ---- W_hh fragments (as lstm_batch.h, WQ form): lane (i = l & 15, q) of tile mt holds gate column 16 mt + i
     f16x8 Wf[4][KSW];
@@ -101,6 +103,22 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
     const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo, p_stride = a.p_stride;
     const unsigned tag_hi = a.tag_epoch << 12;
     const int t_begin = a.t_begin, t_end = a.t_end;
+    // row sums of the layer's output from the all-ones tile (LstmBArgs::rs_dir, lstm_batch.h).  This kernel does NOT write the next
+    // GEMM's A planes (LstmBArgs::planes is ignored: at twelve waves per workgroup there is no register left for it -- 39 spilled
+    // with it); contexts of more than 32 lanes keep split_planes_kernel for the planes (the same bits) and take only the row sums here.
+    float *const rsp = (a.rs_dir[target] && slice == 0) ? a.rs_dir[target] + (size_t)dir * a.rs_rows : nullptr;
+    // row sum of the row that group g's turn of step sm multiplied with (lstm_batch.h, row_sum_of_step): by the last multiply wave,
+    // in the shadow of its next poll for that group
+    auto row_sum_of_step = [&](int g, int sm) {
+        if (rsp && w == NDW - 1 && l < NB && sm > 0 && ((lane_mask >> (NB * g + l)) & 1ull))
+        {
+            float hp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ww = 0; ww < NDW; ++ww)
+                hp[ww] = hsw[(((sm & 1) * G + g) * 8 + ww) * 16 + l];
+            rsp[(size_t)(NB * g + l) * a.Tp + (size_t)(dir == 0 ? sm - 1 : T - sm)] = tree_sum<NDW>(hp) * (1.0f / 16384.0f);
+        }
+    };
 
     typedef __attribute__((address_space(3))) void *lds_ptr;
     typedef const __attribute__((address_space(1))) void *glb_ptr;
@@ -182,6 +200,8 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
 #pragma unroll
                                 for (int i = 0; i < 4; ++i)
                                     v[ks][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gran_rs, goff[ks] + i * 64 * NB, 0, 16)); // sc1
+                            if (spins == 0)
+                                row_sum_of_step(g, step - 1);
                             unsigned bad = 0;
 #pragma unroll
                             for (int ks = 0; ks < KSW; ++ks)
@@ -237,6 +257,8 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                     for (int ks = 0; ks < KSW; ++ks)
                         accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, hf[ks][ph], accH, 0, 0, 0);
                 const float hs = wof2 * accH[0];
+                if (rsp && q == 0) // sum over this wave's k-range of h'_{step-1}, group g, lane n
+                    hsw[(((step & 1) * G + g) * 8 + w) * 16 + n] = accH[0];
                 float4 *pw = part + ((size_t)((g * 8 + w) * 4) * 4 + q) * NB + n;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -323,6 +345,10 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
         a.prof[(a.layer * 2 + pw_idx) * 8 + 6] = 0;
         a.prof[(a.layer * 2 + pw_idx) * 8 + 7] = 0;
     }
+    if (t_end > t_begin)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            row_sum_of_step(g, t_end - 1);
     if (gate_wave) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
 #pragma unroll
         for (int g = 0; g < G; ++g)
