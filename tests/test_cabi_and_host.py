@@ -25,6 +25,23 @@ def test_hip_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.HIP_SYMBOLS) == names
 
 
+def test_cu_reservations_are_requests_per_device_not_one_global_value(pkg):
+    """umx_hip_gate_reserve (include/umx_hip.h): two multi-GPU drivers on one device each file a request; destroying
+    one gives back ITS request only; giving back a request that was never filed is an error.  Pure host state: runs without a GPU."""
+    lib = ctypes.CDLL(str(ROOT / "umx.cpp_amd" / "libumx_hip.so"))
+    lib.umx_hip_gate_reserve.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.umx_hip_gate_reserve.restype = ctypes.c_int
+    dev = 5  # any slot of the per-device table
+    assert lib.umx_hip_gate_reserve(dev, 0) == 0        # clean slate
+    assert lib.umx_hip_gate_reserve(dev, 16) == 0       # driver A
+    assert lib.umx_hip_gate_reserve(dev, 8) == 0        # driver B
+    assert lib.umx_hip_gate_reserve(dev, -16) == 0      # A is destroyed: B's request stays
+    assert lib.umx_hip_gate_reserve(dev, -16) != 0      # nothing of that size left to give back
+    assert lib.umx_hip_gate_reserve(dev, -8) == 0       # B is destroyed
+    assert lib.umx_hip_gate_reserve(dev, -8) != 0
+    assert lib.umx_hip_gate_reserve(-1, 4) != 0         # no such device
+
+
 def test_host_side_fp16_encoding_of_weight_planes_is_round_to_nearest_even(pkg):
     """csrc/gemm_planes.h re-encodes weights as fp16 planes on the host at load time (u8 / u16 integers exactly, fp32
     weights as two split terms): its fp32 -> fp16 conversion against numpy's, over random values of every magnitude

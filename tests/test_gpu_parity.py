@@ -440,6 +440,11 @@ def test_error_behaviour_of_the_c_abi(pkg, model_small, small):
     del broken[2]["fc2.weight"]
     with pytest.raises((pkg.UmxError, KeyError)):
         pkg.Engine(broken, 128, N)
+    # track lanes x segment length beyond the 32-bit addressing of the plane GEMMs' operands: refused at create, before any large
+    # allocation (48 lanes x 3,900 frames: the second fp16 plane of fc1's operand would start past 2^31 bytes)
+    with pytest.raises(pkg.UmxError) as e:
+        pkg.Engine(targets, 128, 3900 * 1024, tracks=48)
+    assert e.value.code == pkg.ERR_ARG and "32-bit" in str(e.value)
     # still alive
     w = pkg.ggml.synth_audio(N, 800)
     eng.stream_reset()
