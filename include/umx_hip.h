@@ -40,7 +40,9 @@ extern "C" {
 #define UMX_FLAG_NO_WIENER 0x1      /* BASELINE config 2: mix-phase estimate only (wiener.cpp:96-109) */
 #define UMX_FLAG_SKIP_TARGET(t) (0x100 << (t)) /* BASELINE config 1 (vocals only = skip 0,1,2) */
 #define UMX_FLAG_LSTM_STEPWISE 0x10 /* one launch per timestep instead of the persistent kernel */
-#define UMX_FLAG_DEBUG_TAPS 0x20    /* keep the filtered spectrograms for umx_hip_read_tap("y") (the fused kernel does not write them otherwise) */
+#define UMX_FLAG_DEBUG_TAPS 0x20    /* keep what only the taps read: the filtered spectrograms for umx_hip_read_tap("y") (the fused kernel does not
+                                     * write them otherwise) and, in track-batched contexts, the fp32 rows of the recurrence's layers ("lstm",
+                                     * "lstm_l0", "lstm_l1": the batched kernels write the next GEMM's fp16 planes instead, csrc/lstm_batch.h) */
 #define UMX_FLAG_LSTM_FORCE_SAFE 0x40 /* persistent kernel: never take the intra-XCD fast protocol */
 #define UMX_FLAG_LSTM_PROFILE 0x80  /* persistent kernel: record per-phase cycle counters */
 #define UMX_FLAG_DEBUG_LSTM_ABORT 0x2000 /* testing: the persistent LSTM launch of layer 1 gives up half way, exactly as if a
@@ -288,7 +290,8 @@ int umx_hip_hidden(const umx_hip_ctx *ctx);
 /* Stage taps for parity tests (D2H copy of an intermediate of the LAST inferred segment).
  * what: "spec" [2][T][2049] complex | "mix_mag" [2][T][2049] | "x" [T][2976] |
  *       "fc1" [T][H] | "lstm" [T][H] | "fc2" [T][H] | "mask" [T][4098] |
- *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex (needs UMX_FLAG_DEBUG_TAPS) | "max_abs" [1];
+ *       "target_mag" [2][T][2049] | "y" [2][T][2049] complex (needs UMX_FLAG_DEBUG_TAPS; so does "lstm" in a track-batched
+ *       context) | "max_abs" [1];
  *       ("mix_mag", "target_mag" and "mask" are not buffers of the engine any more -- fc3 writes the mask in a padded
  *       layout and the Wiener kernels form mask x |X| in registers -- a tap kernel computes them on demand with the
  *       device functions the hot kernels use, so they hold the bits the pipeline works with)
