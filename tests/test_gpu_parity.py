@@ -316,7 +316,7 @@ def test_device_resident_track_equals_host_split_and_shift(pkg, small):
 
 def test_fused_wiener_istft_equals_the_unfused_kernels_bitwise(pkg, model_small, monkeypatch):
     """csrc/wiener_istft.h (gains + filter + inverse STFT frame in one kernel: the track-batched default) must give the
-    bits of the separate filter kernel (generic complex 2x2 arithmetic, wiener_apply_kernel) followed by the separate
+    bits of the separate filter kernel (wiener_apply_kernel: the same per-bin functions, one bin per thread) followed by the separate
     inverse STFT (UMX_WIENER=stats4: the single-track default), with and without the EM step (BASELINE config 2),
     including the y tap."""
     import torch

@@ -162,7 +162,7 @@ struct Lane
 {
     TargetAct ta[4];
     float2 *spec = nullptr, *y = nullptr, *frames = nullptr;
-    float *x = nullptr, *wpart = nullptr, *R = nullptr, *Rc = nullptr;
+    float *x = nullptr, *wpart = nullptr, *Rc = nullptr;
     unsigned *maxabs = nullptr;
 };
 
@@ -507,7 +507,6 @@ struct umx_hip_ctx
         ls.mag = (size_t)2 * T * MAGP;
         ls.part = std::max((size_t)4 * nbatch * NBINS * 9, nchunk * 4 * 5 * NBINS);
         ls.rc = (size_t)4 * NBINS * 4;
-        ls.r8 = (size_t)4 * NBINS * 8;
         ls.frames = (size_t)4 * T * NFFT;
         ls.y = (size_t)4 * 2 * T * NBINS;
         return ls;
@@ -1228,7 +1227,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             // pointers and cover all active lanes in one launch (common.h LaneSet)
             const WienerStrides ls = lane_strides();
             float2 *spec_all, *y_all, *frames_all;
-            float *wpart_all, *R_all, *Rc_all;
+            float *wpart_all, *Rc_all;
             unsigned *maxabs_all;
             if (int rc = dalloc(&spec_all, (size_t)B * ls.spec))
                 return rc;
@@ -1237,8 +1236,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             if (int rc = dalloc(&frames_all, (size_t)B * ls.frames))
                 return rc;
             if (int rc = dalloc(&wpart_all, (size_t)B * ls.part))
-                return rc;
-            if (int rc = dalloc(&R_all, (size_t)B * ls.r8))
                 return rc;
             if (int rc = dalloc(&Rc_all, (size_t)B * ls.rc))
                 return rc;
@@ -1252,7 +1249,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 L.y = y_all + (size_t)ln * ls.y;
                 L.frames = frames_all + (size_t)ln * ls.frames;
                 L.wpart = wpart_all + (size_t)ln * ls.part;
-                L.R = R_all + (size_t)ln * ls.r8;
                 L.Rc = Rc_all + (size_t)ln * ls.rc;
                 L.maxabs = maxabs_all + ln;
             }
@@ -2015,7 +2011,7 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
     {
         // two sources per thread (measured: 4 per thread 0.151, 2: 0.128, 1: 0.131 ms per track)
         hipLaunchKernelGGL(wiener_stats4_kernel<2>, dim3((NBINS + 63) / 64, nchunk * lanes.count, 2), dim3(64), 0, st, L0.spec, wm0, T, L0.maxabs, L0.wpart, lanes, ls);
-        hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4, lanes.count), dim3(256), 0, st, L0.wpart, T, L0.Rc, wiener_fused ? nullptr : L0.R, lanes, ls);
+        hipLaunchKernelGGL(wiener_finish4_kernel, dim3(bt, 4, lanes.count), dim3(256), 0, st, L0.wpart, T, L0.Rc, lanes, ls);
         if (!wiener_fused)
             for (int i = 0; i < lanes.count; ++i)
             {
@@ -2023,7 +2019,7 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
                 WienerMags wm;
                 for (int s = 0; s < 4; ++s)
                     wm.m[s] = L.ta[s].mag;
-                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.R, L.y);
+                hipLaunchKernelGGL(wiener_apply_kernel, dim3(bt, T), dim3(256), 0, st, L.spec, wm, T, L.maxabs, L.Rc, L.y);
             }
     }
     OlaOut oo;

@@ -8,7 +8,7 @@
 //   pass 1  wiener_stats4_kernel  per (200-frame batch, bin), all sources: sum_f y y^H and sum_f v, in the reference's
 //                                 batch structure (wiener.cpp:212-258)
 //   pass 2  wiener_finish4_kernel R_j(b) = (sum of batch sums, in batch order) / (eps + sum v)
-//   pass 3  wiener_apply_kernel   per (f, b): Cxx, closed-form 2x2 inverse (wiener.cpp:54-84), gains, y_j = G_j x,
+//   pass 3  wiener_apply_kernel   per (f, b): Cxx, closed-form 2x2 inverse (wiener.cpp:54-84), y_j = v_j R_j (Cxx^-1 x)
 //                                 * max_abs -> y [4][2][T][2049]   (single-track contexts; track-batched contexts fuse
 //                                 this pass with the inverse STFT: wiener_istft.h)
 // The target magnitudes arrive as MASKS [2][T][MAGP] (gemm_common.h): mag_j = mask_j x |X| (inference.cpp:175-183) is
@@ -34,95 +34,6 @@ __device__ __forceinline__ float2 unit_phasor(float2 x)
 __device__ __forceinline__ float wiener_max_abs(const unsigned *maxabs_bits)
 {
     return fmaxf(1.0f, __uint_as_float(*maxabs_bits) / WIENER_SCALE); // wiener.cpp:51
-}
-
-// y_j(c) scaled down by max_abs exactly like wiener.cpp:133-146 (component / max_abs)
-__device__ __forceinline__ float2 wiener_y0(float mag, float2 x, float max_abs)
-{
-    const float2 ph = unit_phasor(x);
-    return make_float2((mag * ph.x) / max_abs, (mag * ph.y) / max_abs);
-}
-
-// grid (ceil(B/256), T).  y: [4][2][T][2049] complex
-__global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restrict__ spec, WienerMags mags,
-                                                           int T, const unsigned *__restrict__ maxabs_bits,
-                                                           const float *__restrict__ R, float2 *__restrict__ y)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (b >= NBINS)
-        return;
-    const float max_abs = wiener_max_abs(maxabs_bits);
-    const float reg = sqrtf(WIENER_EPS); // wiener.cpp:165
-    const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
-    const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
-    const float2 X0 = spec[i0], X1 = spec[i1];
-    const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
-    const float2 x0 = make_float2(X0.x / max_abs, X0.y / max_abs); // wiener.cpp:118-130
-    const float2 x1 = make_float2(X1.x / max_abs, X1.y / max_abs);
-    float v[4];
-    float2 Rr[4][2][2];
-    float2 C[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-    {
-        const float2 ya = wiener_y0(mags.m[s][j0] * h0, X0, max_abs); // inference.cpp:175-183: mask x |X|
-        const float2 yb = wiener_y0(mags.m[s][j1] * h1, X1, max_abs);
-        const float ra = ya.x + ya.y, rb = yb.x + yb.y;
-        float sum = 0.f;
-        sum += (ra * ra) + (0.f * 0.f);
-        sum += (rb * rb) + (0.f * 0.f);
-        v[s] = sum / 2;
-        const float4 *rp = reinterpret_cast<const float4 *>(R + ((size_t)s * NBINS + b) * 8);
-        const float4 r01 = rp[0], r23 = rp[1];
-        Rr[s][0][0] = make_float2(r01.x, r01.y);
-        Rr[s][0][1] = make_float2(r01.z, r01.w);
-        Rr[s][1][0] = make_float2(r23.x, r23.y);
-        Rr[s][1][1] = make_float2(r23.z, r23.w);
-#pragma unroll
-        for (int c1 = 0; c1 < 2; ++c1)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-            { // wiener.cpp:307-325: Cxx += reg(c1,c2) + v * R   (F6: once per source)
-                const float2 term = make_float2((c1 == c2 ? reg : 0.f) + v[s] * Rr[s][c1][c2].x,
-                                                0.f + v[s] * Rr[s][c1][c2].y);
-                C[c1][c2].x += term.x;
-                C[c1][c2].y += term.y;
-            }
-    }
-    // invert4D wiener.cpp:54-84
-    const float2 det = csub(cmul(C[0][0], C[1][1]), cmul(C[0][1], C[1][0]));
-    const float nrm = det.x * det.x + det.y * det.y;
-    const float2 invDet = make_float2(det.x / nrm, -det.y / nrm);
-    const float2 nInv = make_float2(-invDet.x, -invDet.y);
-    float2 Ci[2][2];
-    Ci[0][0] = cmul(invDet, C[1][1]);
-    Ci[0][1] = cmul(nInv, C[0][1]);
-    Ci[1][0] = cmul(nInv, C[1][0]);
-    Ci[1][1] = cmul(invDet, C[0][0]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-    {
-        float2 g[2][2];
-#pragma unroll
-        for (int c1 = 0; c1 < 2; ++c1)
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-            { // wiener.cpp:343-376
-                float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int c3 = 0; c3 < 2; ++c3)
-                    acc = cadd(acc, cmul(Rr[s][c1][c3], Ci[c3][c2]));
-                g[c1][c2] = make_float2(acc.x * v[s], acc.y * v[s]);
-            }
-        float2 o[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int c1 = 0; c1 < 2; ++c1) // wiener.cpp:381-400
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2)
-                o[c2] = cadd(o[c2], cmul(g[c2][c1], c1 == 0 ? x0 : x1));
-        y[(((size_t)s * 2 + 0) * T + f) * NBINS + b] = make_float2(o[0].x * max_abs, o[0].y * max_abs);
-        y[(((size_t)s * 2 + 1) * T + f) * NBINS + b] = make_float2(o[1].x * max_abs, o[1].y * max_abs);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -172,7 +83,7 @@ __device__ __forceinline__ void wiener_frame_load(WienerFrame<NS> &w, const floa
 // Lanes: blockIdx.y = entry * nchunk + chunk; spec, mags, maxabs_bits and part are lane 0's (WienerStrides apart per lane).
 struct WienerStrides
 {
-    size_t spec, mag, part, rc, r8, frames, y; // elements between consecutive track lanes
+    size_t spec, mag, part, rc, frames, y; // elements between consecutive track lanes
 };
 template <int NS>
 __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
@@ -208,7 +119,7 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
         for (int s = 0; s < NS; ++s)
         {
             const float t0 = w.m0[s] * h0, t1 = w.m1[s] * h1; // target magnitude = mask x |X| (inference.cpp:175-183)
-            // wiener_y0 with the division by max_abs as an exact 3-instruction quotient (div_by, common.h)
+            // y_j(c) = mag * phasor / max_abs (wiener.cpp:133-146), the division as an exact 3-instruction quotient (div_by, common.h)
             const float2 y0 = make_float2(div_by(t0 * p0.x, max_abs, rmax), div_by(t0 * p0.y, max_abs, rmax));
             const float2 y1 = make_float2(div_by(t1 * p1.x, max_abs, rmax), div_by(t1 * p1.y, max_abs, rmax));
             // v = 1/2 sum_c (Re + Im)^2   wiener.cpp:187-202 (F5)
@@ -256,9 +167,9 @@ __global__ __launch_bounds__(64) void wiener_stats4_kernel(const float2 *__restr
     }
 }
 
-// grid (ceil(B/256), 4).  Rc: [4][2049][4] = {R00, Re R01, Im R01, R11}; R8 (optional): [4][2049][8]
+// grid (ceil(B/256), 4).  Rc: [4][2049][4] = {R00, Re R01, Im R01, R11}
 __global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__restrict__ part, int T, float *__restrict__ Rc,
-                                                             float *__restrict__ R8, LaneSet lanes, WienerStrides ls)
+                                                             LaneSet lanes, WienerStrides ls)
 {
     const int b = blockIdx.x * 256 + threadIdx.x, src = blockIdx.y;
     if (b >= NBINS)
@@ -267,8 +178,6 @@ __global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__rest
         const int ln = lanes.id[blockIdx.z]; // grid (ceil(B/256), 4, lanes)
         part += (size_t)ln * ls.part;
         Rc += (size_t)ln * ls.rc;
-        if (R8)
-            R8 += (size_t)ln * ls.r8;
     }
     constexpr int CPB = WIENER_BATCH / WIENER_CHUNK;
     const int nchunk = (T + WIENER_CHUNK - 1) / WIENER_CHUNK;
@@ -291,45 +200,32 @@ __global__ __launch_bounds__(256) void wiener_finish4_kernel(const float *__rest
     }
     const float4 r = make_float4(acc[0] / weight, acc[1] / weight, acc[2] / weight, acc[3] / weight); // wiener.cpp:259-269
     *reinterpret_cast<float4 *>(Rc + ((size_t)src * NBINS + b) * 4) = r;
-    if (R8) // the eight-float form wiener_apply_kernel reads: R00, R01, R10 = conj(R01), R11
-    {
-        float4 *o = reinterpret_cast<float4 *>(R8 + ((size_t)src * NBINS + b) * 8);
-        o[0] = make_float4(r.x, 0.f, r.y, r.z);
-        o[1] = make_float4(r.y, -r.z, r.w, 0.f);
-    }
 }
 
-// The per-bin part of wiener_apply_kernel, split in two so that the fused kernel can hold many bins in registers:
+// The per-bin arithmetic of the filter, split in two so that the fused kernel (wiener_istft.h) can hold its bins in registers:
 // WienerBin = everything that does not depend on the source whose output is being formed.
+//
+// y_j = G_j x with G_j = v_j R_j Cxx^-1 (wiener.cpp:343-400) is formed as  y_j = v_j * (R_j * (Cxx^-1 x)):  the reference builds the
+// 2 x 2 complex gain of every source first (two matrix products and a scaling per source and bin) and then applies it; the product
+// Cxx^-1 x does not depend on the source, so one matrix-vector product per bin and one per source give the same y_j with 25 instead
+// of 73 operations per source and bin -- in a kernel bound by its vector-instruction count (wiener_istft.h: -12 %).  The two forms
+// differ by rounding only (the sums are reassociated: measured against the oracle, which keeps the reference's order, in
+// tests/test_gpu_parity.py).  Everything up to Cxx^-1 keeps the reference's operations and order.
 struct WienerBin
 {
-    // inverse of Cxx (wiener.cpp:54-84).  Cxx = sum_s (sqrt(eps) I + v_s R_s) is Hermitian bit for bit like the R_s
-    // (real diagonal, C10 = conj(C01) exactly), its determinant is exactly real, and so its inverse is Hermitian too:
-    // four floats {Ci00, Re Ci01, Im Ci01, Ci11}
-    float ci00, ci01x, ci01y, ci11;
-    float2 x0, x1; // mixture / max_abs
+    float2 t0, t1; // Cxx^-1 x, x = mixture / max_abs (wiener.cpp:118-130)
     float v[4];    // source PSDs
 };
 
-__device__ __forceinline__ void wiener_expand(float4 rc, float2 (&Rr)[2][2])
-{
-    Rr[0][0] = make_float2(rc.x, 0.f);
-    Rr[0][1] = make_float2(rc.y, rc.z);
-    Rr[1][0] = make_float2(rc.y, -rc.z);
-    Rr[1][1] = make_float2(rc.w, 0.f);
-}
-
-// Both functions are the generic complex 2x2 arithmetic of wiener_apply_kernel with the structural zeros taken out: R_j,
-// Cxx and its inverse are Hermitian with exactly real diagonals (above), so every product with an exact zero and every
-// sum with one is dropped -- x * 0 is a zero and y + 0 is y, so the VALUES are those of the generic form (only the sign
-// of a zero can differ), at about half the instructions; the remaining operations keep the generic form's order and
-// rounding.  tests/test_gpu_parity.py compares the fused kernel against wiener_apply_kernel bit for bit.
+// R_j, Cxx and its inverse are Hermitian with exactly real diagonals (the statistics pass below; Cxx = sum_s (sqrt(eps) I + v_s R_s);
+// its determinant is exactly real): four floats {M00, Re M01, Im M01, M11} carry each, and products with the structural zeros are
+// not formed.
 __device__ __forceinline__ void wiener_bin_setup(float2 X0, float2 X1, const float (&m0)[4], const float (&m1)[4],
                                                  const float4 (&rc)[4], float max_abs, float rmax, WienerBin &w)
 {
     const float reg = sqrtf(WIENER_EPS); // wiener.cpp:165
-    w.x0 = make_float2(div_by(X0.x, max_abs, rmax), div_by(X0.y, max_abs, rmax)); // wiener.cpp:118-130
-    w.x1 = make_float2(div_by(X1.x, max_abs, rmax), div_by(X1.y, max_abs, rmax));
+    const float2 x0 = make_float2(div_by(X0.x, max_abs, rmax), div_by(X0.y, max_abs, rmax)); // wiener.cpp:118-130
+    const float2 x1 = make_float2(div_by(X1.x, max_abs, rmax), div_by(X1.y, max_abs, rmax));
     const float2 p0 = unit_phasor(X0), p1 = unit_phasor(X1);
     float c00 = 0.f, c11 = 0.f, c01x = 0.f, c01y = 0.f; // Cxx = [[c00, c01], [conj(c01), c11]]
 #pragma unroll
@@ -349,43 +245,61 @@ __device__ __forceinline__ void wiener_bin_setup(float2 X0, float2 X1, const flo
         c01y += v * rc[s].z;
         c11 += reg + v * rc[s].w;
     }
-    // invert4D wiener.cpp:54-84: det = c00 c11 - c01 conj(c01) is real; 1/det is formed as det / |det|^2 like the generic form
+    // invert4D wiener.cpp:54-84: det = c00 c11 - c01 conj(c01) is real; 1/det is formed as det / |det|^2 like the reference's form
     const float det = c00 * c11 - (c01x * c01x + c01y * c01y);
     const float idet = det / (det * det);
-    w.ci00 = idet * c11;
-    w.ci01x = -idet * c01x;
-    w.ci01y = -idet * c01y;
-    w.ci11 = idet * c00;
+    const float p = idet * c11, qx = -idet * c01x, qy = -idet * c01y, r = idet * c00; // Cxx^-1 = [[p, q], [conj(q), r]]
+    // t = Cxx^-1 x
+    w.t0 = make_float2(p * x0.x + (qx * x1.x - qy * x1.y), p * x0.y + (qx * x1.y + qy * x1.x));
+    w.t1 = make_float2((qx * x0.x + qy * x0.y) + r * x1.x, (qx * x0.y - qy * x0.x) + r * x1.y);
 }
 
-// y_s = G_s x * max_abs for one source (wiener.cpp:343-400): G = (R Cxx^-1) v, R = [[a, b], [conj(b), d]], Cxx^-1 = [[p, q], [conj(q), r]]
+// y_s = v_s R_s t * max_abs for one source: R = [[a, b], [conj(b), d]]
 __device__ __forceinline__ void wiener_bin_apply(const WienerBin &w, int s, float4 rc, float max_abs, float2 (&o)[2])
 {
     const float vs = s == 0 ? w.v[0] : s == 1 ? w.v[1] : s == 2 ? w.v[2] : w.v[3]; // selects: w stays in registers
-    const float a = rc.x, bx = rc.y, by = rc.z, d = rc.w, p = w.ci00, qx = w.ci01x, qy = w.ci01y, r = w.ci11;
-    float2 g[2][2];
-    // g00 = a p + b conj(q)
-    g[0][0] = make_float2(a * p + (bx * qx + by * qy), by * qx - bx * qy);
-    // g01 = a q + b r
-    g[0][1] = make_float2(a * qx + bx * r, a * qy + by * r);
-    // g10 = conj(b) p + d conj(q)
-    g[1][0] = make_float2(bx * p + d * qx, -(by * p + d * qy));
-    // g11 = conj(b) q + d r
-    g[1][1] = make_float2((bx * qx + by * qy) + d * r, bx * qy - by * qx);
+    const float a = rc.x, bx = rc.y, by = rc.z, d = rc.w;
+    const float2 t0 = w.t0, t1 = w.t1;
+    const float2 u0 = make_float2(a * t0.x + (bx * t1.x - by * t1.y), a * t0.y + (bx * t1.y + by * t1.x));
+    const float2 u1 = make_float2((bx * t0.x + by * t0.y) + d * t1.x, (bx * t0.y - by * t0.x) + d * t1.y);
+    const float g = vs * max_abs; // wiener.cpp:408-422 undoes the scaling of wiener.cpp:115-146
+    o[0] = make_float2(u0.x * g, u0.y * g);
+    o[1] = make_float2(u1.x * g, u1.y * g);
+}
+
+// The separate filter pass of single-track contexts (track-batched contexts: wiener_istft.h).  R: the four-float form.
+// grid (ceil(B/256), T).  y: [4][2][T][2049] complex
+__global__ __launch_bounds__(256) void wiener_apply_kernel(const float2 *__restrict__ spec, WienerMags mags,
+                                                           int T, const unsigned *__restrict__ maxabs_bits,
+                                                           const float *__restrict__ R, float2 *__restrict__ y)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (b >= NBINS)
+        return;
+    const float max_abs = wiener_max_abs(maxabs_bits), rmax = 1.0f / max_abs;
+    const size_t i0 = ((size_t)0 * T + f) * NBINS + b, i1 = ((size_t)1 * T + f) * NBINS + b;
+    const size_t j0 = mask_index(0, T, f, b), j1 = mask_index(1, T, f, b);
+    const float2 X0 = spec[i0], X1 = spec[i1];
+    const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
+    float m0[4], m1[4];
+    float4 rc[4];
 #pragma unroll
-    for (int c1 = 0; c1 < 2; ++c1)
+    for (int s = 0; s < 4; ++s)
+    {
+        m0[s] = mags.m[s][j0] * h0; // inference.cpp:175-183: mask x |X|
+        m1[s] = mags.m[s][j1] * h1;
+        rc[s] = *reinterpret_cast<const float4 *>(R + ((size_t)s * NBINS + b) * 4);
+    }
+    WienerBin wb;
+    wiener_bin_setup(X0, X1, m0, m1, rc, max_abs, rmax, wb);
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-            g[c1][c2] = make_float2(g[c1][c2].x * vs, g[c1][c2].y * vs);
-    o[0] = make_float2(0.f, 0.f);
-    o[1] = make_float2(0.f, 0.f);
-#pragma unroll
-    for (int c1 = 0; c1 < 2; ++c1) // wiener.cpp:381-400
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2)
-            o[c2] = cadd(o[c2], cmul(g[c2][c1], c1 == 0 ? w.x0 : w.x1));
-    o[0] = make_float2(o[0].x * max_abs, o[0].y * max_abs);
-    o[1] = make_float2(o[1].x * max_abs, o[1].y * max_abs);
+    for (int s = 0; s < 4; ++s)
+    {
+        float2 o[2];
+        wiener_bin_apply(wb, s, rc[s], max_abs, o);
+        y[(((size_t)s * 2 + 0) * T + f) * NBINS + b] = o[0];
+        y[(((size_t)s * 2 + 1) * T + f) * NBINS + b] = o[1];
+    }
 }
 
 // "no Wiener" configuration (BASELINE config 2): y_j = mag_j * exp(i arg X)  (wiener.cpp:96-109 only)
