@@ -392,10 +392,10 @@ def main():
         planes = flavour in ("planes", "bf16x3")  # both run on the bf16 matrix cores
         gname = "gemm_planes_kernel" if flavour == "planes" else "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel"
         exact = planes and not args.expanded_weights and not args.u8_dequant  # integer weights as exact bf16 terms
-        # products per fp32 product: planes = 2 fp16 planes per activation x 1 (u8) or 2 (u16 / fp32) weight planes;
+        # products per fp32 product: planes = 2 fp16 planes per activation x 1 weight plane (u8), or 3 of the 4 products with the 2 (u16 / fp32);
         # bf16x3 = 3 bf16 terms per activation x 1 exact plane (u8) or the 6-product rule
         p8 = (2 if exact else 4) if flavour == "planes" else (3 if exact else 6)
-        p16 = 4 if flavour == "planes" else 6
+        p16 = 3 if flavour == "planes" else 6  # (a2 x the low weight plane, 2^-22 of the sum, is not formed: csrc/gemm_planes.h)
         # (the PMC summary holds demangled names: "void umx::gemm_planes_kernel<1, 1, 4, 4>(umx::GemmPArgs)" = <MODE, planes of B, WM, WN>)
         # 256 x 256 launches run the ping-pong form of the plane GEMM (csrc/gemm_planes_pp.h), unless UMX_GEMM_PP says otherwise
         pp = flavour == "planes" and os.environ.get("UMX_GEMM_PP") is None and B * T >= 4096
@@ -509,7 +509,7 @@ def main():
                                         "batched, matrix cores (lstm_batch_kernel)") if batched else "single-track, VALU (lstm_persistent_kernel)"),
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
                        "gemm": (flavour + (" (fp16 matrix cores, f32 accumulate: activations split once into 2 fp16 planes of the power-of-two "
-                                           "scaled row, u8 weights exact in 1 plane (2 products), u16 weights exact in 2 planes (4 products), "
+                                           "scaled row, u8 weights exact in 1 plane (2 products), u16 weights exact in 2 planes, fp16(q) + remainder (3 products: a2 x remainder, 2^-22, is not formed), "
                                            "LDS-DMA staging, 256x256 tiles over all track lanes)" if flavour == "planes" else
                                            " (fp32 operands split into 3 bf16 terms while staged, 3 / 6 products)" if flavour == "bf16x3"
                                            else " MFMA")),

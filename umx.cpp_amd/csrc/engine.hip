@@ -61,9 +61,9 @@ struct QMat
     float s[2] = {1.f, 1.f}, o[2] = {0.f, 0.f};
 };
 
-// A GEMM weight as fp16 planes [nbp][N][K] (gemm_planes.h): u8 -> 1 exact plane of q - 128, u16 -> 2 exact planes
-// 256 (qh - 128), ql - 128, fp32 -> 2 split terms of w / s with s a power of two; (scale, offset + c scale) per file
-// tensor (W_ih: two).
+// A GEMM weight as fp16 planes [nbp][N][K] (gemm_planes.h): u8 -> 1 exact plane of q - 128, u16 -> 2 planes whose sum is
+// exactly q - 32896: fp16(q - 32896) and the remainder (an integer of at most 16), fp32 -> 2 split terms of w / s with s a
+// power of two; (scale, offset + c scale) per file tensor (W_ih: two).
 struct PMat
 {
     unsigned short *p = nullptr;
@@ -752,9 +752,11 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                     d[k] = f16_rne_bits((float)static_cast<const uint8_t *>(tv->data)[(size_t)sr * cols + k] - 128.0f);
                 else
                 {
-                    const unsigned q = static_cast<const uint16_t *>(tv->data)[(size_t)sr * cols + k];
-                    d[k] = f16_rne_bits(256.0f * ((float)(q >> 8) - 128.0f));
-                    d[plane + k] = f16_rne_bits((float)(q & 255u) - 128.0f);
+                    // q - 32896 (= 256 (qh - 128) + (ql - 128): the constant of the affine map below) as fp16 + exact remainder:
+                    // |remainder| <= 16 = 2^-11 of the plane above it, so that a2 x remainder need not be formed (gemm_planes.h)
+                    const float pq = (float)static_cast<const uint16_t *>(tv->data)[(size_t)sr * cols + k] - 32896.0f;
+                    d[k] = f16_rne_bits(pq);
+                    d[plane + k] = f16_rne_bits(pq - f16_bits_to_float(d[k]));
                 }
             }
         }

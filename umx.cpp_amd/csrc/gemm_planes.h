@@ -401,9 +401,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 16) ? 1 : 2) void gemm_pl
             {                                                                                                        \
                 GP_TERM(1, 0, kk) GP_TERM(0, 0, kk)                                                                  \
             }                                                                                                        \
-            else /* B = P_hi + P_lo: a2 P_lo, a2 P_hi, a1 P_lo, a1 P_hi */                                           \
+            else /* B = P_hi + P_lo, |P_lo| <= 2^-11 |P_hi|: a2 P_hi, a1 P_lo, a1 P_hi (a2 P_lo, 2^-22 of the sum, is not formed) */ \
             {                                                                                                        \
-                GP_TERM(1, 1, kk) GP_TERM(1, 0, kk) GP_TERM(0, 1, kk) GP_TERM(0, 0, kk)                              \
+                GP_TERM(1, 0, kk) GP_TERM(0, 1, kk) GP_TERM(0, 0, kk)                                                \
             }                                                                                                        \
         }                                                                                                            \
     }

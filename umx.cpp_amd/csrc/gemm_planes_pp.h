@@ -138,7 +138,7 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         }                                                                                                            \
         else                                                                                                         \
         {                                                                                                            \
-            PP_TERM(1, NBP - 1, kl) PP_TERM(1, 0, kl) PP_TERM(0, NBP - 1, kl) PP_TERM(0, 0, kl)                      \
+            PP_TERM(1, 0, kl) PP_TERM(0, NBP - 1, kl) PP_TERM(0, 0, kl)                                              \
         }                                                                                                            \
     }
     // vmcnt(n): all but the n most recent DMA instructions of this wave have landed (n <= 63: bits 3:0 and 15:14)
