@@ -3,8 +3,8 @@ this is the evidence that the bf16-split matrix-core paths are no less accurate 
 
 Evaluated in float64 from the engine's OWN taps (so that only the stage under test contributes) and the weights the
 reference would use (fl(q*scale+offset), model.cpp:610-616):
-  fc1 -> bn1 -> tanh       K = 2974, u8 weights      [planes: exact one-plane weights, 3 products, affine map on the sum]
-  fc2 -> bn2 -> relu       K = 2048, u16 weights     [planes: exact two-plane weights, 5 products]
+  fc1 -> bn1 -> tanh       K = 2974, u8 weights      [planes: exact one-plane weights, 2 plane products + the row-sum term, affine map on the sum]
+  fc2 -> bn2 -> relu       K = 2048, u16 weights     [planes: two weight planes whose sum is the file's integer, 3 of the 4 plane products + the row-sum term]
   3-layer BiLSTM           2584-step-class recurrence, u8 W_hh, from the engine's fc1 output (torch float64 LSTM)
 for the GEMM flavours planes / bf16x3 (staged split), the single-track (VALU) and the batched (matrix-core) LSTM kernels, and the
 CPU oracle (fp32).  "32 lanes (shipped)" is the configuration the bench times: the launches are large enough for the 256 x 256
