@@ -12,14 +12,17 @@
 //     case (11 + 11 significand bits and the residual's sign), elements more than 2^17 below the row maximum to
 //     2^-39 of it; the inverse scale and the fp32 row sum travel with the row;
 //   * weights are re-encoded ONCE at load time as the integers they are: a u8 weight is q - 128 in ONE fp16 plane
-//     (exact), a u16 weight 256 (qh - 128) + (ql - 128) in TWO (both exact), an fp32 weight two split terms under one
-//     power-of-two scale per file tensor; the affine map of model.cpp:610-616 is applied to the accumulated sum with
-//     the row sum of A:   sum_k a_k (q_k s + o) = s sum_k a_k (q_k - c) + (o + c s) sum_k a_k,   c = 128 or 32896
+//     (exact), a u16 weight q - 32896 in TWO whose sum is exact -- P_hi = fp16(q - 32896) and the remainder P_lo, an
+//     integer of at most 16 (until the end of round 4: the two bytes, 256 (qh - 128) and ql - 128) --, an fp32 weight two
+//     split terms under one power-of-two scale per file tensor; the affine map of model.cpp:610-616 is applied to the
+//     accumulated sum with the row sum of A:   sum_k a_k (q_k s + o) = s sum_k a_k (q_k - c) + (o + c s) sum_k a_k,   c = 128 or 32896
 //   * tiles go global -> LDS by `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write, no VALU), 16 bytes per lane,
 //     the XOR swizzle of the LDS layout folded into WHICH 16 bytes a lane fetches;
-//   * products per 32x32x16 block: 2 (u8 weights) or 4 (u16 / fp32 weights), every one exact in the fp32 accumulator's
-//     input (22-bit products), fp32 accumulate.  (Round 2's first build used three bf16 planes per activation: 3 / 5 / 6
-//     products and 6 bytes per activation element; profiles/r02_v1_*.)
+//   * products per 32x32x16 block: 2 (u8 weights) or 3 (u16 / fp32 weights: a2 P_hi, a1 P_lo, a1 P_hi; with |P_lo| <=
+//     2^-11 |P_hi| the fourth, a2 P_lo, is 2^-22 of the sum -- the size of the activations' own split error -- and is not
+//     formed: DESIGN 4.6 (h)), every one exact in the fp32 accumulator's input (22-bit products), fp32 accumulate.
+//     (Round 2's first build used three bf16 planes per activation: 3 / 5 / 6 products and 6 bytes per activation
+//     element; profiles/r02_v1_*.)
 // Block tile (64 WM) x (64 WN) x 32, WM x WN waves, each 2 x 2 MFMA tiles of v_mfma_f32_32x32x16_f16.  The kernel is
 // bound by the bytes it pulls out of the L2s as much as by the matrix pipe, so the default tile is 256 x 256 (16 waves,
 // one workgroup per CU: half the bytes per flop of 128 x 128), fed by launches that cover every track lane at once

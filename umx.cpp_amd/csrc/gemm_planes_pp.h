@@ -16,7 +16,7 @@
 //
 // so that at any time one wave of a SIMD owns the matrix pipe while the other reads the fragments of its next unit
 // (20 KB per wave: 640 cycles of the LDS port for the four reading waves against 1,024 cycles of matrix instructions).
-// A unit is a whole 32-k tile: 32 matrix instructions and 80 fragment registers for one-plane (u8) weights, 64 and 96 for
+// A unit is a whole 32-k tile: 32 matrix instructions and 80 fragment registers for one-plane (u8) weights, 48 and 96 for
 // two-plane (u16) ones, beside the 128 accumulator registers of the 128 x 64 wave tile.  Group 0 issues all LDS-DMA (in its M phase, into the stage both groups finished reading one barrier ago) and
 // waits for a tile at the end of the C phase before the M phase that reads it: a tile has two trips to arrive, as in
 // gemm_planes_kernel.  Every accumulator sees the same sequence of matrix instructions as there: bit-identical results.
