@@ -17,6 +17,7 @@ What the JSON line holds (one line, rank 0):
   value_single_segment         BASELINE config 3 as it is worded -- ONE track, its 60 s segments one after the other
                    through the single-track engine (two segments in flight: the exact wavefront), HBM resident;
   value_single_segment_pcie    ... the same with pinned host buffers; lone_segment_ms = one segment with nothing else in flight
+                               (lone_segment_ms_latency_context: the same in a one-track context created with UMX_CREATE_GEMM_PLANES)
   checked_max_abs  after the timed region: two lanes of the batched engine, from a reset state, against the single-track
                    engine on the same audio (max |difference| over the stems; `outputs_checked` = below 1e-5).  The
                    oracle comparison of this configuration is tests/test_gpu_batch.py (full size, 32 and 48 lanes).
@@ -345,6 +346,24 @@ def main():
                   "lstm_launch_ms": round(lstm1, 4), "lstm_launch_ms_alone": round(sum(alone1[f"lstm_rec{l}"] for l in range(3)) / 3, 4),
                   "checked_max_abs": checked, "checked_lanes": check_lanes if check_stems else None}
         e1.close()
+        # a lone segment in a one-track context created for LATENCY (UMX_CREATE_GEMM_PLANES: the plane GEMMs instead of the staged
+        # ones -- their workgroups do not fit beside two recurrence grids, so segments back to back are slower there, DESIGN 4.3;
+        # the flavour is a property of the context, not of the load: a segment's bits never depend on what else is in flight)
+        if args.gemm is None:
+            try:
+                e1p = pkg.Engine.from_file(wpath, segment_samples=N, device=local_rank, quantised_resident=not args.expanded_weights,
+                                           gemm="planes", tracks=1, lstm_batched=False, u8_dequant=args.u8_dequant)
+                lone_p = []
+                for i in range(8):
+                    t1 = time.perf_counter()
+                    e1p.infer_segment_device(a1.data_ptr(), N, p1[0], flags)
+                    e1p.sync()
+                    if i >= 2:
+                        lone_p.append((time.perf_counter() - t1) * 1e3)
+                single["lone_segment_ms_latency_context"] = round(float(np.median(lone_p)), 3)
+                e1p.close()
+            except Exception as e:  # noqa: BLE001
+                single["lone_segment_ms_latency_context"] = repr(e)
 
     if rank == 0:
         seg_sec = N / 44100.0
@@ -491,6 +510,7 @@ def main():
             "value_single_segment": single["value"] if single else None,
             "value_single_segment_pcie": single["value_pcie"] if single else None,
             "lone_segment_ms": single["lone_segment_ms"] if single else None,
+            "lone_segment_ms_latency_context": single.get("lone_segment_ms_latency_context") if single else None,
             "checked_max_abs": single["checked_max_abs"] if single else None,
             "outputs_checked": (single["checked_max_abs"] is not None and single["checked_max_abs"] < 1e-5) if single else None,
             "value_pcie": (round(world * B * args.steps * seg_sec / dt_pcie, 2) if isinstance(dt_pcie, float) else None),
