@@ -280,6 +280,26 @@ def main():
                     print(f"# lstm {tag} layer {layer} wave {w}: cycles/step poll {c[0] / n:.0f} dot {c[1] / n:.0f} barrier {c[2] / n:.0f} "
                           f"gates {c[3] / n:.0f} failed-polls/step {c[5] / n:.2f} (steps {int(c[4])}) "
                           f"[poll: sleep {c[6] / n:.0f} first-loads {c[7] / n:.0f}]", file=sys.stderr)
+        if not batched:
+            from collections import Counter
+            pl = eng.lstm_placement(8 * (H // 2 // 16))
+            cus = Counter((x, (hw >> 8) & 0xff) for x, _, _, hw in pl)  # (XCC, SE | SH | CU of HW_ID)
+            print(f"# lstm placement: {len(pl)} workgroups on {len(cus)} distinct CUs; CUs holding 2 or more: "
+                  f"{sum(1 for v in cus.values() if v > 1)}; per XCC: {sorted(Counter(x for x, _, _, _ in pl).items())}", file=sys.stderr)
+            # timeline of one workgroup (chain 0, slice 5), 64 steps: per wave the stamps loop top, poll ok, dot end, barrier exit, end
+            nraw = 960 + 64 * 8 * 5
+            buf = (pkg.C.c_ulonglong * nraw)()
+            eng._check(eng.lib.umx_hip_debug_lstm_placement(eng.h, buf, nraw))
+            tr = np.array(buf[960:], dtype=np.int64).reshape(64, 8, 5)
+            if tr.any():
+                base = tr[:, 0, 3]  # wave 0's barrier exit of the step = start of its gate phase
+                rel = tr[1:] - base[:-1, None, None]  # step s+1's stamps relative to the barrier exit that ended step s
+                med = np.median(rel, axis=0)
+                print("# lstm timeline (cycles after the previous barrier exit of wave 0; median of 63 steps): wave: loop-top poll-ok dot-end barrier-exit end", file=sys.stderr)
+                for w in range(8):
+                    print(f"#   wave {w}: " + " ".join(f"{v:6.0f}" for v in med[w]), file=sys.stderr)
+                print(f"#   step period (barrier exit to barrier exit, wave 0): median {np.median(np.diff(base)):.0f} "
+                      f"min {np.diff(base).min()} max {np.diff(base).max()}", file=sys.stderr)
     eng.close()
     del eng, audios, out_sets
     torch.cuda.empty_cache()

@@ -314,6 +314,9 @@ int umx_hip_lstm_mode(umx_hip_ctx *ctx);
 /* UMX_FLAG_LSTM_PROFILE: shader-clock cycles summed over the T steps of each layer, for waves 0 and 1
  * of workgroup (chain 0, slice 0): out48[(layer*2 + wave)*8 + {0 poll, 1 dot, 2 barrier, 3 gates, 4 steps}] */
 int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48);
+/* Where the workgroups of the last profiled one-track recurrence launch ran (UMX_FLAG_LSTM_PROFILE): out[i] for workgroup i =
+ * XCC id << 48 | chain << 40 | slice << 32 | the 32-bit HW_ID register (CU, shader array, shader engine).  n <= 512. */
+int umx_hip_debug_lstm_placement(umx_hip_ctx *ctx, unsigned long long *out, int n);
 /* Debugging (tools/bx_guard.py): queue `launches` guard kernels on a private stream -- each workgroup keeps a 36 KB
  * pattern in LDS and re-verifies it `rounds` times -- beside whatever the caller queues next; launches == 0 waits
  * for them and returns {words found changed, events} in out2.  Used to show that no kernel of this engine writes

@@ -120,6 +120,7 @@ def hip_lib():
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.umx_hip_debug_lstm_placement.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     lib.umx_hip_stream_layer_floats.restype = C.c_size_t
     lib.umx_hip_stream_layer_floats.argtypes = [C.c_void_p]
     lib.umx_hip_stream_get_layer.argtypes = [C.c_void_p, C.c_int, _fp]
@@ -154,7 +155,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
                "umx_hip_stage_times_slot",
-               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile",
+               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
                "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits",
@@ -413,6 +414,13 @@ class Engine:
         self._check(self.lib.umx_hip_debug_lstm_profile(self.h, buf))
         a = np.array(buf[:], dtype=np.uint64).reshape(3, 2, 8)
         return a
+
+    def lstm_placement(self, n=256):
+        """(xcc, chain, slice, HW_ID) of every workgroup of the last profiled one-track recurrence launch."""
+        buf = (C.c_ulonglong * n)()
+        self._check(self.lib.umx_hip_debug_lstm_placement(self.h, buf, n))
+        a = np.array(buf[:], dtype=np.uint64)
+        return [(int(v >> 48) & 15, int(v >> 40) & 255, int(v >> 32) & 255, int(v) & 0xffffffff) for v in a]
 
     def tap(self, what, target=0):
         n = self.lib.umx_hip_read_tap(self.h, what.encode(), target, None, 0)

@@ -421,6 +421,7 @@ struct umx_hip_ctx
     float *backup = nullptr; // [kBackupCalls][3 layers][B * state_floats]: the stream state right before each layer launch
     bool no_recovery = false, recovering = false;
     int recover();
+    int lstm_poll_delay = 0;         // 0 = the kernel's default (LSTM_POLL_DELAY)
     int lstm_threads = LSTM_THREADS; // 512 (two workgroups per CU fit) or 576 (dedicated gate wave)
     int lstm_capacity = 0;           // workgroups of the persistent LSTM kernel that can be co-resident
     unsigned last_flags = 0;
@@ -703,6 +704,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     // Track-batched contexts fuse the Wiener filter with the inverse STFT (wiener_istft.h: one 1024-thread, 136 KB-LDS
     // workgroup per frame); the single-track context keeps the small kernels, which run beside the other slot's LSTM
     // grids (measured: fused 7.85 ms per segment in the pipeline, unfused 7.41).  UMX_WIENER = fused | stats4 | unfused.
+    if (const char *e = getenv("UMX_LSTM_POLL_DELAY")) // tuning: x64 cycles a dot wave of the one-track recurrence sleeps before its first poll
+        lstm_poll_delay = atoi(e);
     wiener_fused = lstm_batched;
     if (const char *e = getenv("UMX_WIENER")) // fused | stats4 (= statistics kernel + separate filter and inverse-STFT kernels)
         wiener_fused = std::string(e) == "fused";
@@ -1261,7 +1264,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             return rc;
         if (int rc = dalloc(&sl.lsync, lsync_words))
             return rc;
-        if (int rc = dalloc(&sl.lprof, 64))
+        if (int rc = dalloc(&sl.lprof, 1024 + 64 * 8 * 5))
             return rc;
         for (int i = 0; i <= ST_COUNT; ++i)
             UMX_HIP_CHECK(hipEventCreate(&sl.ev[i]));
@@ -1460,6 +1463,7 @@ int umx_hip_ctx::run_lstm_layer(Slot &sl, int layer, const int *active, int nact
     a.status = sl.status;
     a.prof = (last_flags & UMX_FLAG_LSTM_PROFILE) ? sl.lprof : nullptr;
     a.force_safe = (last_flags & UMX_FLAG_LSTM_FORCE_SAFE) ? 1 : 0;
+    a.poll_delay = lstm_poll_delay;
     a.Hl = Hl;
     a.S = S;
     a.T = T;
@@ -3362,6 +3366,17 @@ int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48)
         return UMX_ERR_ARG;
     if (ctx->sync_all() != UMX_OK ||
         hipMemcpy(out48, ctx->slot[ctx->cur].lprof, sizeof(unsigned long long) * 48, hipMemcpyDeviceToHost) != hipSuccess)
+        return UMX_ERR_HIP;
+    return UMX_OK;
+}
+
+// where the workgroups of the last profiled one-track recurrence launch ran: out[i] = xcc << 48 | chain << 40 | slice << 32 | HW_ID
+int umx_hip_debug_lstm_placement(umx_hip_ctx *ctx, unsigned long long *out, int n)
+{
+    if (!ctx || !out || n < 0 || n > 960 + 64 * 8 * 5)
+        return UMX_ERR_ARG;
+    if (ctx->sync_all() != UMX_OK ||
+        hipMemcpy(out, ctx->slot[ctx->cur].lprof + 64, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) != hipSuccess)
         return UMX_ERR_HIP;
     return UMX_OK;
 }

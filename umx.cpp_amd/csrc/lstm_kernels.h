@@ -72,6 +72,7 @@ struct LstmArgs
     int Hl, S, T, ldp, ldo, col0, layer, nchains;
     int tmap[4];      // chain>>1 -> target (targets can be skipped: BASELINE config 1)
     int force_safe;   // 1 = never use the intra-XCD protocol (testing)
+    int poll_delay;    // x64 shader cycles a dot wave sleeps behind the barrier before its first poll (0 = LSTM_POLL_DELAY)
     int abort_at;      // testing (UMX_FLAG_DEBUG_LSTM_ABORT): every workgroup gives up at this step as if a poll had timed out
     unsigned tag_base; // granule tag of step s = tag_base + s + 1: unique per launch, so a granule line left in
                        // some L2 by an earlier launch can never pass for this launch's data
@@ -150,6 +151,48 @@ template <bool PRECISE> __device__ __forceinline__ void lstm_cell(float pre, int
     const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
     c = c_t;
     h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
+}
+
+// The same arithmetic as lstm_cell<false>, operation for operation (same bits), written without control flow: the
+// gate wave's phase is ONE dependent chain on the critical path of every step, and the two exec-mask branches the
+// compiler makes of lstm_cell (tanh only in the g lanes, tanh(c) only in the storing lanes) cost more than the few
+// instructions they skip.  Per-lane constants (g lane or not) are loop-invariant registers of the caller.
+struct CellLane
+{
+    unsigned abs_mask; // g lanes: 0x7fffffff (|pre|), others: all ones
+    float zk;          // g lanes: -2, others: -1        (exp argument: -2|x| or -x)
+    unsigned tanh_sel; // g lanes: all ones (take tanh), others 0 (take the sigmoid)
+    __device__ __forceinline__ void init(int lane)
+    {
+        const bool g = (lane & 3) == 2;
+        abs_mask = g ? 0x7fffffffu : 0xffffffffu;
+        zk = g ? -2.0f : -1.0f;
+        tanh_sel = g ? 0xffffffffu : 0u;
+    }
+};
+__device__ __forceinline__ float tanh_from_e_sel(float x, float e, float rcp1pe)
+{
+    const float x2 = x * x;
+    const float big = copysignf((1.0f - e) * rcp1pe, x);
+    const float poly = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.0539682540f, 0.133333333f), -0.333333333f), 1.0f);
+    const bool small = fabsf(x) < 0.125f;
+    return small ? poly : big; // both sides are values already: a v_cndmask, no branch
+}
+__device__ __forceinline__ void lstm_cell_flat(float pre, const CellLane &cl, float &c, float &h)
+{
+    const float xa = __uint_as_float(__float_as_uint(pre) & cl.abs_mask);
+    const float e = exp_hw(cl.zk * xa); // exp(-2|x|) in the g lanes, exp(-x) elsewhere: lstm_cell's argument bit for bit
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    const float th = tanh_from_e_sel(pre, e, r);
+    const int ai = (int)((__float_as_uint(th) & cl.tanh_sel) | (__float_as_uint(r) & ~cl.tanh_sel)); // v_bfi_b32
+    const float i_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x00, 0xF, 0xF, true));
+    const float f_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0x55, 0xF, 0xF, true));
+    const float g_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xAA, 0xF, 0xF, true));
+    const float o_t = __int_as_float(__builtin_amdgcn_update_dpp(0, ai, 0xFF, 0xF, 0xF, true));
+    const float c_t = f_t * c + i_t * g_t; // lstm.cpp:154-156
+    c = c_t;
+    const float e2 = exp_hw(-2.0f * fabsf(c_t));
+    h = o_t * tanh_from_e_sel(c_t, e2, __builtin_amdgcn_rcpf(1.0f + e2)); // lstm.cpp:157
 }
 
 // row_ror:n of a 32-bit value (rotation inside each row of 16 lanes); n is a compile-time constant
@@ -269,12 +312,14 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then abort the launch
 #define LSTM_POLLS_IN_FLIGHT 1 // measured best once two LSTM grids share the chip (2: -3 %, 3: -5 %)
+#define LSTM_TRACE_SLICE 5
+#define LSTM_TRACE_STEP0 1200
 #define LSTM_PROF_WAVE 1 // the dot wave the in-kernel profiler reports beside the gate wave
 #define LSTM_P_BULK 16 // W_ih x + b_ih rows fetched per bulk (multiple of 8, power of two)
 #define LSTM_P_RING (2 * LSTM_P_BULK)
 #define LSTM_GATE_POLL_DELAY 0 // x64 cycles the gate wave waits after publishing before its own first poll
                                // (measured 0..4: 0 is best, its first poll already succeeds)
-#define LSTM_POLL_DELAY 8 // x64 shader cycles a dot wave sleeps after the barrier before its first poll
+#define LSTM_POLL_DELAY 5 // x64 shader cycles a dot wave sleeps after the barrier before its first poll (round 5: 8 -> 5 with the shorter gate phase; 6: +2 %, 4: +2 %, 3: +5 %)
 
 __device__ __forceinline__ unsigned xcc_id()
 {
@@ -465,7 +510,19 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo;
     const unsigned tag_base = a.tag_base;
     const int S = a.S;
+    const int poll_delay = a.poll_delay > 0 ? a.poll_delay : LSTM_POLL_DELAY;
     float hlast = 0.f;
+    // Gate wave, loop-invariant: the per-lane constants of the branch-free cell, and the two stores of a step as buffer
+    // stores whose offset is out of range in the lanes that do not store (one lane per unit does): no exec-mask branch
+    // and no 64-bit address arithmetic on the critical path between h and its publication.
+    CellLane cl;
+    cl.init(l);
+    const bool store_lane = (l & 3) == 0;
+    const __amdgpu_buffer_rsrc_t gran_rs = __builtin_amdgcn_make_buffer_rsrc(a.sync + LSTM_SYNC_HEADER_WORDS, 0, (int)(granule_count(S) * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(outp - unit, 0, 0x7fffffff, 0x00020000);
+    const unsigned goff[2] = {store_lane ? (unsigned)(granule_index(0, chain, unit, S) * 8) : 0x80000000u,
+                              store_lane ? (unsigned)(granule_index(1, chain, unit, S) * 8) : 0x80000000u};
+    const unsigned ooff = store_lane ? (unsigned)unit * 4u : 0x80000000u;
     // W_ih x + b_ih rows come from HBM, and vmcnt retires in order: whichever wave has such a load in flight
     // cannot complete its next hidden-state poll before the row has arrived.  Alone on the chip that is ~750
     // cycles; beside a GEMM or a streaming kernel of the other pipeline slot it is several microseconds, and a
@@ -492,7 +549,10 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         fetch_rows(LSTM_P_BULK);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the rows are in LDS before the first barrier
     }
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): nothing loaded above (bias, state) is still in flight inside the loop
     const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == gw || w == LSTM_PROF_WAVE); // wave-uniform
+    // timeline of the profiler: every wave of (chain 0, slice LSTM_TRACE_SLICE) stamps steps [LSTM_TRACE_STEP0, + 64)
+    const bool trace = a.prof != nullptr && chain == 0 && slice == LSTM_TRACE_SLICE;
     unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
     unsigned prof_spins = 0;
 
@@ -500,7 +560,8 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     {
         const int t = dir == 0 ? step : T - 1 - step;
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        if (prof)
+        const bool stamp = prof || (trace && step >= LSTM_TRACE_STEP0 && step < LSTM_TRACE_STEP0 + 64);
+        if (stamp)
             c0 = clock64();
         if (a.abort_at && step == a.abort_at && tid == 0)
         {
@@ -521,7 +582,8 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 if (FAST)
                 {
                     if (!gate_wave)
-                        __builtin_amdgcn_s_sleep(LSTM_POLL_DELAY);
+                        for (int i = 0; i < poll_delay; ++i)
+                            __builtin_amdgcn_s_sleep(1);
                     else if (LSTM_GATE_POLL_DELAY > 0)
                         __builtin_amdgcn_s_sleep(LSTM_GATE_POLL_DELAY);
                 }
@@ -567,7 +629,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 if ((step & (LSTM_P_BULK - 1)) == 0)
                     fetch_rows(step + LSTM_P_BULK);
             }
-            if (prof)
+            if (stamp)
                 c1 = clock64();
             if constexpr (DPP)
             {
@@ -583,14 +645,12 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                     s0 = __uint_as_float(r01[0]) + __uint_as_float(r01[1]); // p_r + p_{r+2}
                     s1 = __uint_as_float(r23[0]) + __uint_as_float(r23[1]);
                 }
-                const float t0 = s0 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s0), 0x401F)); // xor 16
-                const float t1 = s1 + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(s1), 0x401F));
-                if ((l & 16) == 0) // rows 0 and 2 write; rows 1 and 3 hold the same sums
-                {
-                    float *pp = &(*(part + (step & 1)))[w][4 * (l & 15) + (l >> 5)];
-                    pp[0] = t0;
-                    pp[2] = t1;
-                }
+                // rows r and r ^ 1 meet through ONE v_permlane16_swap of (s0, s1): afterwards row 0 holds both halves of
+                // gate 0, row 1 of gate 2, row 2 of gate 1, row 3 of gate 3 -- every lane ends with one finished column
+                // (the same (p0 + p2) + (p1 + p3) as before, without the LDS round trip of two ds_swizzle)
+                const auto rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(s0), __float_as_uint(s1), false, false);
+                const float tsum = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);
+                (*(part + (step & 1)))[w][4 * (l & 15) + (((l >> 4) & 1) << 1) + (l >> 5)] = tsum;
             }
             else
             {
@@ -607,30 +667,47 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 (*(part + (step & 1)))[w][l] = hadd2(acc);
             }
         }
-        if (prof)
+        // the gate wave's W_ih x + b_ih element of this step has been in the ring for >= LSTM_P_BULK steps: read it before the
+        // barrier, so that behind the barrier only the eight partial sums stand between the wave and the activations
+        float prow = 0.f;
+        if (gate_wave)
+            prow = pbuf[step & (LSTM_P_RING - 1)][l];
+        if (stamp)
             c2 = clock64();
         __syncthreads();
         if (*abort_flag) // uniform after the barrier: every wave leaves, nobody is left spinning on us
             return;
-        if (prof)
+        if (stamp)
             c3 = clock64();
         if (gate_wave)
         {
             __builtin_amdgcn_s_setprio(1); // the serial gate phase wins issue arbitration against dot waves
             float(*pq)[64] = *(part + (step & 1));
             const float s = ((pq[0][l] + pq[1][l]) + (pq[2][l] + pq[3][l])) + ((pq[4][l] + pq[5][l]) + (pq[6][l] + pq[7][l]));
-            const float pre = (pbuf[step & (LSTM_P_RING - 1)][l] + s) + bh;
+            const float pre = (prow + s) + bh; // lstm.cpp:132-140; prow was read from the ring before the barrier
             float h;
-            lstm_cell<PRECISE>(pre, l, c, h);
-            if ((l & 3) == 0)
-            {
-                const unsigned long long gv =
-                    ((unsigned long long)(tag_base + (unsigned)(step + 1)) << 32) | (unsigned long long)__float_as_uint(h);
-                granule_store<FAST>(gran + granule_index(step & 1, chain, unit, S), gv);
-                outp[(size_t)t * ldo] = h;
-                hlast = h;
-            }
+            if constexpr (PRECISE)
+                lstm_cell<true>(pre, l, c, h);
+            else
+                lstm_cell_flat(pre, cl, c, h);
+            typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+            v2u32 gv;
+            gv.x = __float_as_uint(h);
+            gv.y = tag_base + (unsigned)(step + 1);
+            // "the data is the flag": one naturally aligned 8-byte store {value, tag}; FAST = plain (the chain shares one L2), SAFE = sc1
+            __builtin_amdgcn_raw_buffer_store_b64(gv, gran_rs, goff[step & 1], 0, FAST ? 0 : 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), out_rs, ooff, (unsigned)t * (unsigned)ldo * 4u, 0); // lstm.cpp:163-164
+            hlast = h;
             __builtin_amdgcn_s_setprio(0);
+        }
+        if (stamp && !prof)
+        {
+            const long long c4 = clock64();
+            if (l == 0)
+            {
+                unsigned long long *tr = a.prof + 1024 + ((size_t)(step - LSTM_TRACE_STEP0) * 8 + (w & 7)) * 5;
+                tr[0] = c0, tr[1] = c1, tr[2] = c2, tr[3] = c3, tr[4] = c4;
+            }
         }
         if (prof)
         {
@@ -666,6 +743,13 @@ template <int KPW, bool PRECISE> __global__ __launch_bounds__(LSTM_PERSISTENT_TH
         lstm_census(a.sync, a.status, S, nwg, a.force_safe, s_ctl);
     __syncthreads();
     const int chain = s_ctl[0], slice = s_ctl[1];
+    if (a.prof && tid == 0) // placement record of the profiler: where this workgroup runs and which role it took
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        a.prof[64 + blockIdx.x] = ((unsigned long long)(xcc_id() & 15) << 48) | ((unsigned long long)(chain & 0xff) << 40) |
+                                  ((unsigned long long)(slice & 0xff) << 32) | hw;
+    }
     if (s_ctl[3] || chain >= a.nchains) // aborted, or an XCD / block range with no chain to run
         return;
     if (s_ctl[2])
