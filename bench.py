@@ -233,14 +233,21 @@ def main():
     prof_pipelined = eng.lstm_profile() if args.lstm_profile else None
     st = [d for d in (eng.stage_times(slot=i) for i in range(depth)) if d]
     stage_ms = {k: sum(d[k] for d in st) / len(st) for k in st[0]} if st else {}
+    kern_ms = {}
+    ks = [d for d in (eng.stage_kernel_times(slot=i) for i in range(depth)) if d]
+    if ks:
+        kern_ms = {k: sum(d[k] for d in ks) / len(ks) for k in ks[0]}
+    # the same K steps once more, one at a time (a sync after each): min / median show the box's noise beside the mean of the
+    # timed region; the stages of the last one = each kernel alone on the chip
     serial = []
-    stage_alone_ms = {}
-    for _ in range(2):
+    stage_alone_ms, kern_alone_ms = {}, {}
+    for _ in range(max(2, args.steps)):
         t1 = time.perf_counter()
         step()
         eng.sync()
         serial.append((time.perf_counter() - t1) * 1e3)
-        stage_alone_ms = eng.stage_times()
+    stage_alone_ms = eng.stage_times()
+    kern_alone_ms = eng.stage_kernel_times()
     finite = bool(all(torch.isfinite(o).all().item() for st_ in out_sets for o in st_))
     lstm_mode, batched = eng.lstm_mode(), eng.lstm_is_batched()
 
@@ -413,15 +420,19 @@ def main():
         def gemm_entry(stage_keys, work_key, products, name, tneedles):
             # the plane GEMMs cover all track lanes in one launch (the stage also holds the small split_planes launch)
             launches = len(stage_keys) * (1 if flavour == "planes" else B)
-            ms = sum(stage_ms.get(kk, 0.0) for kk in stage_keys) / launches
-            ms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in stage_keys) / launches
+            # launch_ms = the GEMM kernel itself (event between the stage's split kernel and the GEMM ... next stage); stage_ms = with the split kernel
+            stg = sum(stage_ms.get(kk, 0.0) for kk in stage_keys) / launches
+            stg_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in stage_keys) / launches
+            ms = sum(kern_ms.get(kk, stage_ms.get(kk, 0.0)) for kk in stage_keys) / launches
+            ms_alone = sum(kern_alone_ms.get(kk, stage_alone_ms.get(kk, 0.0)) for kk in stage_keys) / launches
             alg = gemm[work_key] * (B if flavour == "planes" else 1)
             issued = alg * products if flavour != "f32" else alg
             peak = BF16_MFMA_PEAK_TF if flavour != "f32" else F32_MFMA_PEAK_TF
             ach = alg / (ms * 1e-3) / 1e12 if ms > 0 else 0.0  # ALGORITHMIC flops / live launch duration
             ach_issued = issued / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"kernel": name, "bound": "mfma", "pipe": "fp16 MFMA" if flavour != "f32" else "fp32 MFMA", "launches_per_step": launches,
-                    "launch_ms": round(ms, 4), "launch_ms_alone": round(ms_alone, 4), "algorithmic_flops_per_launch": alg,
+                    "launch_ms": round(ms, 4), "launch_ms_alone": round(ms_alone, 4), "kernel_ms": round(ms, 4), "stage_ms": round(stg, 4),
+                    "stage_ms_alone": round(stg_alone, 4), "algorithmic_flops_per_launch": alg,
                     "issued_flops_per_launch": issued, "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "frac_issued": round(ach_issued / peak, 4),
                     "frac_alone": round(alg / (ms_alone * 1e-3) / 1e12 / peak, 4) if ms_alone > 0 else None,
@@ -526,7 +537,11 @@ def main():
             "metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg",
             "value": round(value, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (activations as 2 x fp16 planes of the power-of-two-scaled row, integer weights exact in fp16, f32 accumulate on the fp16 matrix cores; fp32-grade: 1.4-2.2x the error of an fp32 evaluation, profiles/r04_accuracy_vs_float64.txt)" if batched else "f32 (dense stack: operands as 3 bf16 terms on the bf16 matrix cores, f32 accumulate; recurrence on the fp32 vector pipe)",
+            "data": "synthetic",
+            "ms_per_step_min": round(min(serial), 3), "ms_per_step_median": round(float(np.median(serial)), 3),
+            "ms_per_step_note": f"min / median over {len(serial)} further steps run one at a time (sync after each); ms_per_step is the mean of the timed region",
             "value_single_segment": single["value"] if single else None,
             "value_single_segment_pcie": single["value_pcie"] if single else None,
             "lone_segment_ms": single["lone_segment_ms"] if single else None,
@@ -629,7 +644,8 @@ def bench_track_mode(args, pkg, mg, dist, world, rank, local_rank, dev, wpath):
         nseg = -(-(L + 22050 - 4033) // int(0.75 * N))
         line = {"metric": "realtime-factor (audio-sec/wall-sec) UMX-L 4-stem, 60 s seg", "value": round(steps * secs / dt, 2),
                 "unit": "x realtime", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32 (dense stack: operands as 3 bf16 terms on the bf16 matrix cores, f32 accumulate; recurrence on the fp32 vector pipe)", "data": "synthetic",
                 "config": {"workload": f"UMX-L full-track segmented inference: one {secs:g} s track, {nseg} segments over {world} MI355X as "
                                        f"{G} target group(s) x {world // G} segment-pipeline stage(s), exact LSTM state carry (per-layer (h, c) by "
                                        "RCCL send/recv between the engines' HBM state buffers, sends on their own stream and communicator), "

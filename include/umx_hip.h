@@ -305,6 +305,10 @@ int umx_hip_stage_times(umx_hip_ctx *ctx, const char **names, float *ms, int cap
 /* Same for pipeline slot 0 or 1 (consecutive segments alternate slots; when two segments were queued
  * back to back their spans overlap, so a stage's time includes interference from the other slot). */
 int umx_hip_stage_times_slot(umx_hip_ctx *ctx, int slot_index, const char **names, float *ms, int cap);
+/* The same stages with the MAIN kernel alone where a stage launches a preparing kernel first (the GEMM stages of plane
+ * contexts: split_planes_kernel, then the GEMM): the time from an event recorded between the two to the next stage's
+ * event.  Stages without such a kernel report their stage time.  slot_index < 0: the slot of the last call. */
+int umx_hip_stage_kernel_times_slot(umx_hip_ctx *ctx, int slot_index, float *ms, int cap);
 /* 1 if the LSTM layers of the last segment ran in the persistent (one launch per layer) kernel,
  * 0 if the per-timestep driver was used (flag, unsupported hidden size, or grid not co-resident). */
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);

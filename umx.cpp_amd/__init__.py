@@ -117,6 +117,7 @@ def hip_lib():
     lib.umx_hip_read_tap.argtypes = [C.c_void_p, C.c_char_p, C.c_int, _fp, C.c_size_t]
     lib.umx_hip_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), _fp, C.c_int]
     lib.umx_hip_stage_times_slot.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), _fp, C.c_int]
+    lib.umx_hip_stage_kernel_times_slot.argtypes = [C.c_void_p, C.c_int, _fp, C.c_int]
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
@@ -154,7 +155,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_stream_reset", "umx_hip_stream_get", "umx_hip_stream_set", "umx_hip_infer_segment",
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
-               "umx_hip_stage_times_slot",
+               "umx_hip_stage_times_slot", "umx_hip_stage_kernel_times_slot",
                "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
@@ -456,6 +457,14 @@ class Engine:
         else:
             n = self.lib.umx_hip_stage_times_slot(self.h, slot, names, ms, 32)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def stage_kernel_times(self, slot=None):
+        """Like stage_times, but a GEMM stage of a plane context without its split kernel (umx_hip_stage_kernel_times_slot)."""
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = self.lib.umx_hip_stage_times_slot(self.h, 0, names, (C.c_float * 32)(), 32)
+        m = self.lib.umx_hip_stage_kernel_times_slot(self.h, -1 if slot is None else slot, ms, 32)
+        return {names[i].decode(): float(ms[i]) for i in range(min(n, m))}
 
 
 # ------------------------------------------------------------------ C++17 host library (umx_host.h)

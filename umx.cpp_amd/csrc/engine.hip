@@ -179,6 +179,8 @@ struct Slot
     unsigned *status = nullptr, *lsync = nullptr;
     unsigned long long *lprof = nullptr;
     hipEvent_t ev[ST_COUNT + 1] = {};
+    hipEvent_t evk[ST_COUNT] = {}; // GEMM stages of plane contexts: recorded between the stage's split kernel and its GEMM kernel
+    bool evk_set[ST_COUNT] = {};
     hipEvent_t rec_done[3] = {}; // LSTM layer l of this slot's segment has finished (state updated)
     // host-pointer entry points (see umx_hip_infer_batch_async): the download of call k's stems is queued on the OTHER slot's
     // stream, behind call k + 1's kernels
@@ -1268,6 +1270,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             return rc;
         for (int i = 0; i <= ST_COUNT; ++i)
             UMX_HIP_CHECK(hipEventCreate(&sl.ev[i]));
+        for (int i : {ST_FC1, ST_IH0, ST_IH1, ST_IH2, ST_FC2, ST_FC3})
+            UMX_HIP_CHECK(hipEventCreate(&sl.evk[i]));
         for (int l = 0; l < 3; ++l)
             UMX_HIP_CHECK(hipEventCreateWithFlags(&sl.rec_done[l], hipEventDisableTiming));
     }
@@ -1922,6 +1926,11 @@ void umx_hip_ctx::launch_gemm_lanes(Slot &sl, hipStream_t st, int nb, const floa
             const int from_layer = which == SP_LA ? 0 : which == SP_LB ? 1 : which == SP_CATR ? 2 : -1;
             if (from_layer < 0 || !sl.lstm_wrote_planes[from_layer]) // else: written by the recurrence
                 launch_split(sl.lane[l0], l1 - l0, st, which, active, nact);
+            {
+                // the stage's kernel time without its split kernel (umx_hip_stage_kernel_times): stage event ... this event ... next stage event
+                const int stg = mode == G_FC1 ? ST_FC1 : mode == G_IH ? ST_IH0 + 2 * layer : mode == G_FC2 ? ST_FC2 : ST_FC3;
+                sl.evk_set[stg] = sl.evk[stg] && hipEventRecord(sl.evk[stg], st) == hipSuccess;
+            }
             launch_gemm_planes(sl.lane[l0], l1 - l0, st, mode, layer, active, nact, dbg);
         }
         else
@@ -2778,8 +2787,12 @@ void umx_hip_destroy(umx_hip_ctx *ctx)
     {
         Slot &sl = ctx->slot[si];
         for (int i = 0; i <= ST_COUNT; ++i)
+        {
             if (sl.ev[i])
                 (void)hipEventDestroy(sl.ev[i]);
+            if (i < ST_COUNT && sl.evk[i])
+                (void)hipEventDestroy(sl.evk[i]);
+        }
         for (int l = 0; l < 3; ++l)
             if (sl.rec_done[l])
                 (void)hipEventDestroy(sl.rec_done[l]);
@@ -3341,6 +3354,28 @@ int umx_hip_stage_times_slot(umx_hip_ctx *ctx, int slot_index, const char **name
         (void)hipEventElapsedTime(&t, sl.ev[i], sl.ev[i + 1]);
         if (names)
             names[i] = kStageNames[i];
+        if (ms)
+            ms[i] = t;
+    }
+    return ST_COUNT;
+}
+
+// per stage: the time from the event recorded BEHIND the stage's split kernel to the next stage's event, i.e. the stage's main
+// kernel alone (GEMM stages of plane contexts); the stage time where there is no such event.  Same conventions as umx_hip_stage_times_slot.
+int umx_hip_stage_kernel_times_slot(umx_hip_ctx *ctx, int slot_index, float *ms, int cap)
+{
+    if (ctx && slot_index < 0)
+        slot_index = ctx->cur;
+    if (!ctx || slot_index >= ctx->nslots)
+        return 0;
+    Slot &sl = ctx->slot[slot_index];
+    if (!sl.have_times || ctx->sync_all() != UMX_OK)
+        return 0;
+    const int n = std::min(cap, (int)ST_COUNT);
+    for (int i = 0; i < n; ++i)
+    {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, sl.evk_set[i] ? sl.evk[i] : sl.ev[i], sl.ev[i + 1]);
         if (ms)
             ms[i] = t;
     }

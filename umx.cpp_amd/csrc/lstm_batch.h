@@ -313,6 +313,10 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
         fetch_rows(t_begin + bulk);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
     }
+    // vmcnt(0) for EVERY wave: what was loaded above (bias, state, weights) is then known to have arrived, and the compiler does
+    // not place a "wait for everything" in front of the bias add of the gate phase -- which, inside the loop, is a wait for the
+    // acknowledgements of the row / plane stores issued a few hundred cycles earlier, on the hand-off's critical path
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads(); // the first rows are read before the first step's barrier
     const bool prof = a.prof != nullptr && group == 0 && chain == 0 && slice == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
     const int pw_idx = w == 0 ? 0 : 1;
@@ -544,8 +548,10 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
                 b3 = cvt_pk_bf16(r2, 0.f) & 0xffffu;
             }
             const unsigned mine12 = b1 | (b2 << 16);
-            const unsigned other12 = (unsigned)__builtin_amdgcn_ds_swizzle((int)mine12, 0x401F); // lane ^ 16
-            const unsigned other3 = WQ ? 0u : (unsigned)__builtin_amdgcn_ds_swizzle((int)b3, 0x401F);
+            // the partner's halves (lane ^ 16; only the even rows, which publish, use them): one v_permlane16_swap per value puts
+            // row r + 1 into row r of the second result -- a VALU exchange instead of the LDS round trip of ds_swizzle
+            const unsigned other12 = __builtin_amdgcn_permlane16_swap(mine12, mine12, false, false)[1];
+            const unsigned other3 = WQ ? 0u : __builtin_amdgcn_permlane16_swap(b3, b3, false, false)[1];
             if (lane_on)
             {
                 c = c_t;

@@ -139,6 +139,10 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
         fetch_rows(t_begin + bulk);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
     }
+    // vmcnt(0) for EVERY wave: what was loaded above (bias, state, weights) is then known to have arrived, and the compiler does
+    // not place a "wait for everything" in front of the bias add of the gate phase -- which, inside the loop, is a wait for the
+    // acknowledgements of the row / plane stores issued a few hundred cycles earlier, on the hand-off's critical path
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads(); // the first rows are read before the first barrier of the loop
 
     // in-kernel profiler (UMX_FLAG_LSTM_PROFILE; bench.py --lstm-profile): wave 0 (a multiply wave) and wave 8 (a gate wave) of
@@ -312,7 +316,7 @@ __device__ __forceinline__ void lstmb2_body(const LstmBArgs &a, int chain, int s
                 const _Float16 h1 = (_Float16)hs14, h2 = (_Float16)(hs14 - (float)h1);
                 const unsigned b1 = __builtin_bit_cast(unsigned short, h1), b2 = __builtin_bit_cast(unsigned short, h2);
                 const unsigned mine12 = b1 | (b2 << 16);
-                const unsigned other12 = (unsigned)__builtin_amdgcn_ds_swizzle((int)mine12, 0x401F); // lane ^ 16
+                const unsigned other12 = __builtin_amdgcn_permlane16_swap(mine12, mine12, false, false)[1]; // lane ^ 16 for the even rows (lstm_batch.h)
                 if (lane_on[g])
                 {
                     c[g] = c_t;

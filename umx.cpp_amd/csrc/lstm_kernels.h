@@ -533,12 +533,18 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     typedef __attribute__((address_space(3))) void *lds_ptr;
     typedef const __attribute__((address_space(1))) void *glb_ptr;
     const unsigned pbuf_lds = (unsigned)(size_t)(lds_ptr)&pbuf[0][0]; // LDS byte address of the ring
-    auto fetch_rows = [&](int first_row) { // this wave's share (rows first_row + 2w, + 2w + 1) of a bulk
+    // Waves 1..7 fetch (row j of a bulk: wave 1 + j % 7), at the TOP of the step that frees the slots and in front of their
+    // sleep: the rows have the sleep and the poll's round trip (~900 cycles) to land before anything of that wave waits on
+    // vmcnt.  Wave 0 fetches nothing: in the 512-thread form it is the gate wave, and its queue stays free for the gate
+    // phase's stores and its own poll.  (Round 1-4 issued the fetch behind the successful poll, i.e. in front of the
+    // multiply: any vmcnt wait the compiler places there -- it does -- then stalls the wave for the rows' HBM latency
+    // once per bulk, 3-4 % of a launch.)
+    auto fetch_rows = [&](int first_row) {
 #pragma unroll
-        for (int j = 0; j < LSTM_P_BULK / 8; ++j)
+        for (int j = 0; j < LSTM_P_BULK; ++j)
         {
-            const int r = first_row + w * (LSTM_P_BULK / 8) + j;
-            if (r < T)
+            const int r = first_row + j;
+            if (w == 1 + j % 7 && r < T)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(Pp + (size_t)(dir == 0 ? r : T - 1 - r) * ldp),
                                                  (lds_ptr)(size_t)(pbuf_lds + 256u * (unsigned)(r & (LSTM_P_RING - 1))), 4, 0, 0);
         }
@@ -547,9 +553,9 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     {
         fetch_rows(0);
         fetch_rows(LSTM_P_BULK);
-        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the rows are in LDS before the first barrier
     }
-    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): nothing loaded above (bias, state) is still in flight inside the loop
+    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): nothing loaded above (bias, state, the first rows) is still in flight inside the loop
+    __syncthreads(); // the gate wave reads row 0 of the ring in front of the loop's first barrier: every wave's rows are in LDS
     const bool prof = a.prof != nullptr && chain == 0 && slice == 0 && (w == gw || w == LSTM_PROF_WAVE); // wave-uniform
     // timeline of the profiler: every wave of (chain 0, slice LSTM_TRACE_SLICE) stamps steps [LSTM_TRACE_STEP0, + 64)
     const bool trace = a.prof != nullptr && chain == 0 && slice == LSTM_TRACE_SLICE;
@@ -570,6 +576,11 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
         }
         if (dot_wave)
         {
+            // rows [step + BULK, step + 2 BULK) replace rows [step - BULK, step), all consumed: this workgroup's gate wave read
+            // row step - 1 before the barrier that ended step - 1.  They land in LDS before this wave's poll completes
+            // (vmcnt in order), i.e. before it enters the next barrier, and are first read BULK barriers later.
+            if (step > 0 && (step & (LSTM_P_BULK - 1)) == 0)
+                fetch_rows(step + LSTM_P_BULK);
             if (step > 0)
             {
                 // wait for h_{step-1}: tag == step, slot (step-1)&1.  A granule keeps its tag until it is
@@ -623,11 +634,6 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 }
                 prof_spins = spins;
                 hval = __uint_as_float((unsigned)x);
-                // rows [step + BULK, step + 2 BULK) replace rows [step - BULK, step), all consumed: every slice
-                // has published step - 1.  They land in LDS before this wave's next poll completes (vmcnt in
-                // order) and are first read BULK barriers later.
-                if ((step & (LSTM_P_BULK - 1)) == 0)
-                    fetch_rows(step + LSTM_P_BULK);
             }
             if (stamp)
                 c1 = clock64();
@@ -674,7 +680,9 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
             prow = pbuf[step & (LSTM_P_RING - 1)][l];
         if (stamp)
             c2 = clock64();
-        __syncthreads();
+        // workgroup barrier for LDS only (the partial sums of this step): __syncthreads() is also a release fence for global
+        // memory, i.e. s_waitcnt vmcnt(0) in front of the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (*abort_flag) // uniform after the barrier: every wave leaves, nobody is left spinning on us
             return;
         if (stamp)
