@@ -250,6 +250,7 @@ def main():
     kern_alone_ms = eng.stage_kernel_times()
     finite = bool(all(torch.isfinite(o).all().item() for st_ in out_sets for o in st_))
     lstm_mode, batched = eng.lstm_mode(), eng.lstm_is_batched()
+    lstm_kernel = eng.lstm_kernel_name()  # what the engine launched, not a guess from the lane count
 
     # ---- value_pcie: pinned host buffers in and out, the same number of steps timed the same way
     dt_pcie = None
@@ -462,12 +463,10 @@ def main():
             lp = 2 if (not args.expanded_weights and not args.u8_dequant) else 6  # u8 W_hh: 1 fp16 plane x 2 fp16 planes of h
             groups = (B + 15) // 16  # the matrix instruction is 16 tracks wide: one MFMA phase per group of 16 lanes
             lstm_issued = rec * 16 * groups * lp * (1.25 if lp == 2 else 1.0)  # + the all-ones tile of the u8 form
-            # 17 .. 32 lanes: two groups side by side (lstm_batchs_kernel) unless UMX_LSTM_GROUPED=0; 33 .. 48: the groups in turn
-            lname = "lstm_batch_kernel" if groups == 1 else \
-                "lstm_batchs_kernel" if groups == 2 and os.environ.get("UMX_LSTM_GROUPED") != "0" and H >= 512 else "lstm_batch2_kernel"
+            lname = lstm_kernel
         else:
             lstm_issued = lstm_alg
-            lname = "lstm_persistent_kernel" if lstm_mode >= 1 else "lstm_step_kernel"
+            lname = lstm_kernel
         lach = lstm_alg / (lms * 1e-3) / 1e12 if lms > 0 else 0.0
         # `achieved` / `frac`: ALGORITHMIC flops per launch / live launch duration / peak of the pipe the kernel issues on
         # (the batched kernels: fp16 matrix cores; the single-track kernel: fp32 VALU = the fp32 roof).  `frac_issued`

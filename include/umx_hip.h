@@ -269,8 +269,9 @@ int umx_hip_segment_finish_device(umx_hip_ctx *ctx, float *const out_dev[4]);
 int umx_hip_segment_discard(umx_hip_ctx *ctx); /* closes the phased segment where it stands (a rank that only contributes magnitudes) */
 /* Persistent LSTM launches of every context on `device` leave `cus` compute units out of their co-residency budget
  * (the admission gate of umx_hip_sync's comment): room for kernels that are not this engine's and that may sit on a CU
- * for a long time -- RCCL's send / recv kernels in host/mgpu.cpp.  Process-wide, per device: cus > 0 files a request (the largest
- * outstanding one applies), -cus gives one request of that size back (UMX_ERR_ARG if there is none), 0 drops every request. */
+ * for a long time -- RCCL's send / recv kernels in host/mgpu.cpp.  Process-wide, per device: cus > 0 files a request (the SUM of
+ * the outstanding ones applies, at most half the chip: every driver keeps its own transfer kernels resident), -cus gives one
+ * request of that size back (UMX_ERR_ARG if there is none), 0 drops every request (tests only). */
 int umx_hip_gate_reserve(int device, int cus);
 void *umx_hip_phase_stream(umx_hip_ctx *ctx);
 float *umx_hip_stream_state_device(umx_hip_ctx *ctx);
@@ -312,6 +313,9 @@ int umx_hip_stage_kernel_times_slot(umx_hip_ctx *ctx, int slot_index, float *ms,
 /* 1 if the LSTM layers of the last segment ran in the persistent (one launch per layer) kernel,
  * 0 if the per-timestep driver was used (flag, unsupported hidden size, or grid not co-resident). */
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);
+/* The recurrence kernel the last LSTM layer launch used: "lstm_persistent_kernel" / "lstm_step_kernel" (one track),
+ * "lstm_batch_kernel" (<= 16 lanes), "lstm_batchs_kernel" (17..32 side by side), "lstm_batch2_kernel" (groups in turn). */
+const char *umx_hip_lstm_kernel_name(const umx_hip_ctx *ctx);
 /* 0 = per-timestep driver, 1 = persistent kernel with the placement-independent (sc1) hand-off,
  * 2 = persistent kernel whose census found every chain on one XCD (intra-L2 hand-off); < 0 on error */
 int umx_hip_lstm_mode(umx_hip_ctx *ctx);

@@ -30,8 +30,12 @@
  *
  * Failure: a persistent-LSTM timeout on any rank (another process holding the CUs) is found by every rank through the
  * status all-reduce before rank 0 hands anything out, and the whole track is run again once, the rank concerned on its
- * per-step LSTM driver (bit-identical).  Any other error aborts this rank's communicators (ncclCommAbort) and returns;
- * the other ranks then block in RCCL until their launcher tears the job down (torchrun does when one rank exits).
+ * per-step LSTM driver (bit-identical).  Any other error aborts this rank's communicators (ncclCommAbort) and returns.
+ * No rank waits for ever on a peer: every host-side wait of a track polls its streams against a deadline
+ * (environment UMX_MGPU_TIMEOUT_MS, default 120000) and asks the communicators for asynchronous errors
+ * (ncclCommGetAsyncError); on expiry or on an error the rank aborts its communicators -- its queued transfers end, its
+ * streams drain -- and umx_mgpu_separate_track returns UMX_ERR_TIMEOUT ("watchdog: ...") or UMX_ERR_HIP.  A driver whose
+ * communicators were aborted refuses further tracks; destroy it and create a new one (a new rendezvous).
  */
 #ifndef UMX_MGPU_H
 #define UMX_MGPU_H

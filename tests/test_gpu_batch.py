@@ -13,7 +13,7 @@ from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
 TOL_STAGE, TOL_WAVE = 2e-5, 1e-4  # parity bounds (test_gpu_parity.py)
-REG_STAGE, REG_Y, REG_WAVE = 5e-6, 1e-4, 1e-5  # regression bounds beside them: measured ~1e-6 / ~3e-5 / <= 2e-6
+REG_STAGE, REG_Y, REG_WAVE = 5e-6, 3e-5, 1e-5  # regression bounds beside them: measured ~1e-6 / <= 1.2e-5 / <= 2e-6
 
 
 def _oracle_track(po, om, hidden, waves, n_buf):

@@ -63,6 +63,40 @@ def test_rccl_loopback_executes_every_hop_and_equals_the_one_gpu_driver(pkg, tmp
     eng.close()
 
 
+def test_watchdog_ends_a_wait_for_a_peer_that_never_sends(pkg, tmp_path, monkeypatch):
+    """host/mgpu.cpp: every host-side wait of a track polls its streams against a deadline (UMX_MGPU_TIMEOUT_MS) and asks the
+    communicators for asynchronous errors.  In loopback the engine's stream is held in front of one state hop for twice the
+    deadline (UMX_MGPU_DEBUG_STALL: a sleeping host function; an unmatched receive is refused by RCCL's group call outright): to
+    this rank that is what a peer that never posts its side of a transfer looks like.  The call must come back with the
+    watchdog's error after the deadline (not after the stall, not never), the driver must refuse further tracks, destroy must
+    return, and a fresh driver on the same engine must work again, bit for bit."""
+    import time
+    H, N = 1024, 24 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=79), H, compress=False)
+    eng = pkg.Engine.from_file(path, N)
+    wave = pkg.ggml.synth_audio(int(N * 2.6), 840)
+    ref = eng.separate(wave, shift_offset=4033)
+    monkeypatch.setenv("UMX_MGPU_TIMEOUT_MS", "2000")
+    monkeypatch.setenv("UMX_MGPU_DEBUG_STALL", "1")
+    mg = pkg.MultiGpuTrack(eng, loopback=True)
+    t0 = time.time()
+    with pytest.raises(pkg.UmxError) as ei:
+        mg.separate(wave, shift_offset=4033)
+    assert 1.9 < time.time() - t0 < 30.0
+    assert "watchdog" in str(ei.value)
+    with pytest.raises(pkg.UmxError):  # the communicators were aborted: the driver is dead, not half alive
+        mg.separate(wave, shift_offset=4033)
+    mg.close()
+    monkeypatch.delenv("UMX_MGPU_DEBUG_STALL")
+    mg = pkg.MultiGpuTrack(eng, loopback=True)
+    got = mg.separate(wave, shift_offset=4033)
+    for t in range(4):
+        assert (got[t] == ref[t]).all(), t
+    mg.close()
+    eng.close()
+
+
 def test_mgpu_refuses_a_track_batched_context(pkg, model_small):
     path, om, targets = model_small
     eng = pkg.Engine(targets, 128, 16 * 1024, tracks=2)

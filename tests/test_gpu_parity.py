@@ -26,7 +26,7 @@ TOL_STAGE, TOL_Y, TOL_WAVE, MIN_SDR = 2e-5, 2e-4, 1e-4, 80.0
 # PARITY bounds above (TOL_WAVE = the reference's own 1e-4 of test_dsp.cpp).  REGRESSION bounds beside them (VERDICT round 2,
 # weak #13): what is measured is ~1e-6 per stage (rel L2), ~3e-5 on the Wiener output (the EM step amplifies rounding
 # noise ~100x) and <= 2e-6 on the waveforms, so a change that costs a decimal digit must not pass as "within parity".
-REG_STAGE, REG_Y, REG_WAVE = 5e-6, 1e-4, 1e-5
+REG_STAGE, REG_Y, REG_WAVE = 5e-6, 3e-5, 1e-5  # (REG_Y: round 5, 1e-4 -> 3e-5: measured <= 1.2e-5 since the filter is applied as v R (Cxx^-1 x))
 
 
 def _check_report(rep):

@@ -28,7 +28,7 @@ def reference_ola(frames, n):
 
 def fused_ola(frames, n, run_len, rng):
     T = frames.shape[0]
-    assert run_len >= 3  # engine.hip: a run that is not the last one has at least three frames
+    assert run_len >= 3  # csrc/engine_stages.h: a run that is not the last one has at least three frames
     stem = rng.standard_normal(n).astype(np.float32)  # whatever the buffer held before: must not matter
     kept = {}
     runs = [(f0, min(T, f0 + run_len)) for f0 in range(0, T, run_len)]

@@ -1,12 +1,12 @@
 """The invariant the three-product form of the two-plane GEMMs rests on (csrc/gemm_planes.h).
 
-engine.hip::fill_planes stores a u16 weight q (model.cpp:610-616: w = q * scale + offset) as two fp16 planes
+csrc/engine_init.h::fill_planes stores a u16 weight q (model.cpp:610-616: w = q * scale + offset) as two fp16 planes
 P_hi = fp16(q - 32896), P_lo = (q - 32896) - P_hi, and the kernels form a1 P_hi + a1 P_lo + a2 P_hi but not a2 P_lo.
 That is only as accurate as four products if, for EVERY q,
   * P_hi + P_lo is exactly q - 32896 (the affine map's constants then need no change),
   * P_lo is itself an fp16 number (an integer of at most 16), and
   * |P_lo| <= 2^-11 |P_hi|, so that the product that is not formed is 2^-22 of the sum.
-numpy's float16 is IEEE binary16 with round-to-nearest-even: the rounding f16_rne_bits (engine.hip) implements."""
+numpy's float16 is IEEE binary16 with round-to-nearest-even: the rounding f16_rne_bits (csrc/engine_init.h) implements."""
 import numpy as np
 
 

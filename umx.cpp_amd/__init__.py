@@ -121,6 +121,8 @@ def hip_lib():
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.umx_hip_lstm_kernel_name.restype = C.c_char_p
+    lib.umx_hip_lstm_kernel_name.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_placement.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     lib.umx_hip_stream_layer_floats.restype = C.c_size_t
     lib.umx_hip_stream_layer_floats.argtypes = [C.c_void_p]
@@ -156,7 +158,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
                "umx_hip_stage_times_slot", "umx_hip_stage_kernel_times_slot",
-               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
+               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_lstm_kernel_name", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
                "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits",
@@ -415,6 +417,10 @@ class Engine:
         self._check(self.lib.umx_hip_debug_lstm_profile(self.h, buf))
         a = np.array(buf[:], dtype=np.uint64).reshape(3, 2, 8)
         return a
+
+    def lstm_kernel_name(self):
+        """The recurrence kernel of the last LSTM layer launch (umx_hip_lstm_kernel_name)."""
+        return self.lib.umx_hip_lstm_kernel_name(self.h).decode()
 
     def lstm_placement(self, n=256):
         """(xcc, chain, slice, HW_ID) of every workgroup of the last profiled one-track recurrence launch."""

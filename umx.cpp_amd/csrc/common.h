@@ -48,9 +48,20 @@ __device__ __forceinline__ float div_by(float a, float b, float rcp_b)
     return fmaf(fmaf(-q, b, a), rcp_b, q);
 }
 
-// |X| of one bin exactly as inference.cpp:29 forms it (std::abs of a complex float = hypotf): ONE definition, so that the
-// network input x, the mask x |X| products of the Wiener kernels (inference.cpp:175-183) and the debug taps hold the same bits
-__device__ __forceinline__ float mix_magnitude(float2 z) { return hypotf(z.x, z.y); }
+// |X| of one bin (inference.cpp:29, std::abs of a complex float): ONE definition, so that the network input x, the mask x |X|
+// products of the Wiener kernels (inference.cpp:175-183) and the debug taps hold the same bits.  Round 5: sqrt(re^2 + im^2)
+// (correctly rounded square root of the fp32 sum: within 1.5 ulp of hypotf, which the oracle uses) instead of the device
+// library's hypotf (~25 instructions of scaling the spectrogram's range never needs) -- and the SAME value is the divisor of
+// the unit phasor below, so a bin needs one square root where it took a hypotf, a sqrtf and two IEEE divisions.
+__device__ __forceinline__ float mix_magnitude(float2 z) { return sqrtf(z.x * z.x + z.y * z.y); }
+// X / |X| (std::polar's phase, wiener.cpp:96-109; arg(0) = 0): the quotients are the correctly rounded ones (div_by: the bits of the
+// IEEE divisions this replaced); |X| below 1e-30 (the squares underflow long before) counts as zero
+__device__ __forceinline__ float2 unit_phasor(float2 x)
+{
+    const float a = mix_magnitude(x);
+    const float ra = __builtin_amdgcn_rcpf(a);
+    return a > 1e-30f ? make_float2(div_by(x.x, a, ra), div_by(x.y, a, ra)) : make_float2(1.f, 0.f);
+}
 // element (channel c, frame f, bin b) of a mask plane [2][T][MAGP]
 __device__ __forceinline__ size_t mask_index(int c, int T, int f, int b) { return ((size_t)c * T + f) * MAGP + b; }
 

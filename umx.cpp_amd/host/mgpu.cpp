@@ -19,10 +19,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace
@@ -47,6 +50,11 @@ struct umx_mgpu
     int *status_dev = nullptr;
     long long stats[5] = {0, 0, 0, 0, 0};
     int reserve_device = 0, reserved_cus = 0; // umx_hip_gate_reserve request of this driver (given back by umx_mgpu_destroy)
+    long long timeout_ms = 120000;            // watchdog of every host-side wait of a track (UMX_MGPU_TIMEOUT_MS)
+    int debug_stall_hop = -1;                 // testing (UMX_MGPU_DEBUG_STALL=k, loopback): in front of the k-th state hop the engine's stream
+                                              // is held by a sleeping host function for twice the deadline -- what a peer that
+                                              // does not post its side of a transfer looks like to this rank
+    int hop_counter = 0;
 
     void abort_comms() // a rank that gives up must not leave kernels of its own spinning in RCCL
     {
@@ -87,6 +95,48 @@ struct umx_mgpu
         if (rc_ != UMX_OK)                                                                                           \
             MG_FAIL(rc_, std::string(#expr) + ": " + umx_hip_last_error(m->ctx));                                    \
     } while (0)
+
+// Every host-side wait of a track goes through here: the streams are POLLED (hipStreamQuery), the communicators are asked
+// for asynchronous errors (ncclCommGetAsyncError: a peer that died, a link that failed), and a deadline bounds the whole
+// thing (a peer that simply never posts its side of a transfer reports no error at all).  On any of the three this rank
+// aborts its communicators -- its own RCCL kernels stop spinning, its streams drain -- and returns an error: no rank waits
+// for ever on a peer, with or without a launcher that would tear the job down.
+static void debug_stall_fn(void *ms) { std::this_thread::sleep_for(std::chrono::milliseconds(reinterpret_cast<intptr_t>(ms))); }
+
+static int wait_streams(umx_mgpu *m, std::initializer_list<hipStream_t> streams, const char *what, char *err)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin)
+    {
+        bool all = true;
+        for (hipStream_t s : streams)
+        {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipErrorNotReady)
+                all = false;
+            else if (q != hipSuccess)
+                MG_FAIL(UMX_ERR_HIP, std::string("hipStreamQuery (") + what + "): " + hipGetErrorString(q));
+        }
+        (void)hipGetLastError(); // "not ready" is reported as an error
+        if (all)
+            return UMX_OK;
+        for (ncclComm_t c : {m->ring[0], m->ring[1], m->ring[2], m->gather_comm, m->mag_comm})
+            if (c)
+            {
+                ncclResult_t r = ncclSuccess;
+                if (ncclCommGetAsyncError(c, &r) != ncclSuccess || (r != ncclSuccess && r != ncclInProgress))
+                    MG_FAIL(UMX_ERR_HIP, std::string("RCCL reported an asynchronous error while waiting for ") + what + ": " + ncclGetErrorString(r));
+            }
+        const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > m->timeout_ms)
+            MG_FAIL(UMX_ERR_TIMEOUT, std::string("watchdog: ") + what + " not finished after " + std::to_string(ms) +
+                                         " ms (UMX_MGPU_TIMEOUT_MS): a peer rank is gone or never posted its side of a transfer");
+        if (spin < 2000)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
 
 extern "C" int umx_mgpu_unique_id(char id[UMX_MGPU_ID_BYTES], char *err)
 {
@@ -152,6 +202,10 @@ extern "C" int umx_mgpu_create_ex(umx_mgpu **out, umx_hip_ctx *ctx, int rank, in
     m->rank = rank;
     m->world = world;
     m->loopback = world == 1 && (mgpu_flags & UMX_MGPU_LOOPBACK);
+    if (const char *e = getenv("UMX_MGPU_TIMEOUT_MS"))
+        m->timeout_ms = std::max(1LL, atoll(e));
+    if (const char *e = getenv("UMX_MGPU_DEBUG_STALL"))
+        m->debug_stall_hop = atoi(e);
     m->by_target = mgpu_flags & UMX_MGPU_BY_TARGET;
     const int rc = create_impl(m, id, err);
     if (rc != UMX_OK)
@@ -338,6 +392,8 @@ int separate_once(umx_mgpu *m, const float *audio_host, int length, int shift_of
             else if (loop)
             {
                 // the state segment s - 1 left comes back out of the stash it was sent to (state_of is poisoned in between)
+                if (m->hop_counter++ == m->debug_stall_hop) // testing: the stream stands still as if the peer's side of this hop never came
+                    MG_HIP(hipLaunchHostFunc(st, debug_stall_fn, reinterpret_cast<void *>(static_cast<intptr_t>(2 * m->timeout_ms + 1000))));
                 MG_NCCL(ncclGroupStart());
                 for (int t = 0; t < 4; ++t)
                 {
@@ -537,9 +593,9 @@ int separate_once(umx_mgpu *m, const float *audio_host, int length, int shift_of
 
     // ---- wait, then agree on how it went BEFORE rank 0 hands anything out: a persistent-LSTM timeout on one rank has sent
     // garbage state and stems on (every transfer still took place, so nobody hangs)
-    for (hipStream_t s : {st, ss, ms, gs, as})
-        MG_HIP(hipStreamSynchronize(s));
-    int local = umx_hip_sync(ctx);
+    if (int rc = wait_streams(m, {st, ss, ms, gs, as}, "the track's kernels and transfers", err))
+        return rc;
+    int local = umx_hip_sync(ctx); // (every stream is idle: this collects the engine's status, it does not wait)
     if (local != UMX_OK && local != UMX_ERR_TIMEOUT)
         MG_FAIL(local, std::string("umx_hip_sync: ") + umx_hip_last_error(ctx));
     int global = local;
@@ -548,7 +604,8 @@ int separate_once(umx_mgpu *m, const float *audio_host, int length, int shift_of
         MG_HIP(hipMemcpyAsync(m->status_dev, &local, sizeof(int), hipMemcpyHostToDevice, gs));
         MG_NCCL(ncclAllReduce(m->status_dev, m->status_dev, 1, ncclInt, ncclMax, m->gather_comm, gs));
         MG_HIP(hipMemcpyAsync(&global, m->status_dev, sizeof(int), hipMemcpyDeviceToHost, gs));
-        MG_HIP(hipStreamSynchronize(gs));
+        if (int rc = wait_streams(m, {gs}, "the status all-reduce", err))
+            return rc;
         ++m->stats[0];
     }
     *global_status = global;
@@ -561,7 +618,8 @@ int separate_once(umx_mgpu *m, const float *audio_host, int length, int shift_of
     {
         for (int t = 0; t < 4; ++t) // umx.cpp:136-147: drop the shift
             MG_HIP(hipMemcpyAsync(out_host[t], track[t] + 2 * (size_t)lead, sizeof(float) * 2 * (size_t)length, hipMemcpyDeviceToHost, as));
-        MG_HIP(hipStreamSynchronize(as));
+        if (int rc = wait_streams(m, {as}, "the download of the stems", err))
+            return rc;
     }
     return UMX_OK;
 }
@@ -575,6 +633,7 @@ extern "C" int umx_mgpu_separate_track(umx_mgpu *m, const float *audio_host, int
     if (m->dead)
         MG_FAIL(UMX_ERR_HIP, "umx_mgpu_separate_track: the communicators were aborted after an earlier error");
     m->stats[4] = 0;
+    m->hop_counter = 0;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
         int global = UMX_OK;
