@@ -132,9 +132,9 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--tracks", type=int, default=32,
-                    help="independent tracks per GPU run together (track lanes, 1..48): one step = one 60 s segment of EVERY "
+                    help="independent tracks per GPU run together (track lanes, 1..64): one step = one 60 s segment of EVERY "
                          "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4), > 16 its form that takes groups "
-                         "of 16 lanes side by side (17-32: csrc/lstm_batch.h, lstm_batchs_kernel) or in turn (33-48: csrc/lstm_batch2.h)")
+                         "of 16 lanes side by side (17-32: lstm_batchs_kernel), > 32 two such pairs in turn (lstm_batcht_kernel)")
     ap.add_argument("--batched-lstm", action="store_true", help="use the batched LSTM kernel also with --tracks 1")
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--segment-samples", type=int, default=SEG)
@@ -558,9 +558,11 @@ def main():
                                     "seeded synthetic 44.1 kHz stereo, synthetic UMX-L-shaped u8/u16 ggml weights"),
                        "hidden": H, "segment_samples": N, "frames": T, "stems": 4, "tracks_per_gpu": B,
                        "audio_seconds_per_step": B * seg_sec,
-                       "lstm_kernel": (("batched, matrix cores, groups of 16 lanes in turn (lstm_batch2_kernel)" if B > 32 else
-                                        "batched, matrix cores, two groups of 16 lanes side by side (lstm_batchs_kernel)" if B > 16 else
-                                        "batched, matrix cores (lstm_batch_kernel)") if batched else "single-track, VALU (lstm_persistent_kernel)"),
+                       "lstm_kernel": ({"lstm_batcht_kernel": "batched, matrix cores, two side-by-side pairs of 16-lane groups in turn (lstm_batcht_kernel)",
+                                        "lstm_batch2_kernel": "batched, matrix cores, groups of 16 lanes in turn (lstm_batch2_kernel)",
+                                        "lstm_batchs_kernel": "batched, matrix cores, two groups of 16 lanes side by side (lstm_batchs_kernel)",
+                                        "lstm_batch_kernel": "batched, matrix cores (lstm_batch_kernel)"}.get(lstm_kernel, lstm_kernel)
+                                       if batched else "single-track, VALU (lstm_persistent_kernel)"),
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
                        "gemm": (flavour + (" (fp16 matrix cores, f32 accumulate: activations split once into 2 fp16 planes of the power-of-two "
                                            "scaled row, u8 weights exact in 1 plane (2 products), u16 weights exact in 2 planes, fp16(q) + remainder (3 products: a2 x remainder, 2^-22, is not formed), "

@@ -112,7 +112,7 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
                       const umx_tensor_view *tensors, int n_tensors, unsigned create_flags);
 /* Track batching.  The reference is one track per process (umx.cpp:26-97) and its LSTM is one
  * matrix-vector product per step (lstm.cpp:132-161) -- on a GPU that step is bound by the cross-CU hand-off latency,
- * not by arithmetic.  A context created for n_tracks (1..UMX_MAX_TRACKS = 48) independent tracks holds that many "track lanes", each
+ * not by arithmetic.  A context created for n_tracks (1..UMX_MAX_TRACKS = 64) independent tracks holds that many "track lanes", each
  * with its own streaming LSTM state (= its own std::array<lstm_data,4>, umx.cpp:167-171) and activation buffers;
  * umx_hip_infer_batch* runs one segment of every lane per call, and the recurrence of all lanes is ONE launch per
  * layer in which W_hh.h is a matrix-matrix product on the matrix cores (u8 W_hh as one exact fp16 plane against two fp16
@@ -121,10 +121,12 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
  * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
  * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise.
  * More than 16 lanes (up to UMX_MAX_TRACKS): 17 .. 32 lanes run as two groups of 16 side by side on the chip (csrc/lstm_batch.h,
- * lstm_batchs_kernel: half the hand-off bytes per step; the best operating point per track), 33 .. 48 as groups of 16 in turn
- * through one workgroup (csrc/lstm_batch2.h); the same bits per track either way; needs the u8-resident W_hh of a quantised model. */
+ * lstm_batchs_kernel: half the hand-off bytes per step), 33 .. 64 as two such side-by-side pairs IN TURN through the same
+ * workgroups (lstm_batcht_kernel: one pair's hand-off travels while the other pair's matrix and gate phases run; 33 .. 48 lanes
+ * with UMX_LSTM_GROUPED=0 or an LSTM hidden size other than 256 / 512: groups of 16 in turn, csrc/lstm_batch2.h); the same bits
+ * per track whichever kernel runs; needs the u8-resident W_hh of a quantised model. */
 #define UMX_CREATE_LSTM_BATCHED 0x10u
-#define UMX_MAX_TRACKS 48 /* more than 16 need a quantised model with its u8 W_hh resident (groups of 16 lanes: csrc/lstm_batch.h, lstm_batch2.h) */
+#define UMX_MAX_TRACKS 64 /* more than 16 need a quantised model with its u8 W_hh resident (groups of 16 lanes: csrc/lstm_batch.h, lstm_batch2.h) */
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                           const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
 int umx_hip_n_tracks(const umx_hip_ctx *ctx);

@@ -57,15 +57,16 @@ def test_track_bits_do_not_depend_on_lane_companions_or_batch_size(pkg, tmp_path
     path = str(tmp_path / "m.bin")
     pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=43), H, compress=False)
     track = [pkg.ggml.synth_audio(N, 900 + s) for s in range(NSEG)]
-    other = [pkg.ggml.synth_audio(N, 950 + i) for i in range(48)]
+    other = [pkg.ggml.synth_audio(N, 950 + i) for i in range(64)]
     results = []
     for B, lane, flags in ((1, 0, 0), (4, 2, 0), (16, 13, 0), (4, 1, pkg.FLAG_LSTM_STEPWISE), (4, 3, pkg.FLAG_LSTM_FORCE_SAFE),
                            (32, 5, 0), (32, 29, 0), (20, 17, pkg.FLAG_LSTM_STEPWISE), (24, 21, pkg.FLAG_LSTM_FORCE_SAFE),  # > 16: lstm_batch2.h
-                           (48, 44, 0), (40, 35, pkg.FLAG_LSTM_STEPWISE)):
+                           (48, 44, 0), (40, 35, pkg.FLAG_LSTM_STEPWISE),  # 33 .. 64: lstm_batcht_kernel (two side-by-side pairs in turn)
+                           (64, 50, 0), (64, 3, 0), (56, 33, pkg.FLAG_LSTM_STEPWISE), (40, 19, pkg.FLAG_LSTM_FORCE_SAFE)):
         eng = pkg.Engine.from_file(path, N, tracks=B, lstm_batched=True)
         outs = []
         for s in range(NSEG):
-            batch = [other[(i + s) % 48] for i in range(B)]
+            batch = [other[(i + s) % 64] for i in range(B)]
             batch[lane] = track[s]
             outs.append(eng.infer_batch(batch, flags)[lane])
         results.append((outs, eng.track_stream_get(lane), B, lane, flags))
@@ -152,10 +153,10 @@ def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, 
     H, N = 1024, 40 * 1024
     path = str(tmp_path / "m.bin")
     pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=53), H, compress=False)
-    for B in (20, 32):
+    for B in (20, 32, 40, 64):  # 40, 64 (round 5): lstm_batcht_kernel, two such pairs in turn, against lstm_batch2.h's three groups in turn
         waves = [[pkg.ggml.synth_audio(N - 97 * b, 2300 + 10 * b + s) for b in range(B)] for s in range(2)]
         res = {}
-        for mode in ("0", None, "stepwise"):
+        for mode in (("0", None, "stepwise") if B <= 48 else ("stepwise", None)):  # (more than 48 lanes exist only in the new form)
             if mode == "0":
                 monkeypatch.setenv("UMX_LSTM_GROUPED", "0")
             else:
@@ -165,13 +166,14 @@ def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, 
             outs = [eng.infer_batch(w, flags) for w in waves]
             res[mode] = (outs, [eng.track_stream_get(b) for b in range(B)])
             eng.close()
+        base = "0" if B <= 48 else "stepwise"
         for mode in (None, "stepwise"):
             for s in range(2):
                 for b in range(B):
                     for t in range(4):
-                        assert (res[mode][0][s][b][t] == res["0"][0][s][b][t]).all(), (B, mode, s, b, t)
+                        assert (res[mode][0][s][b][t] == res[base][0][s][b][t]).all(), (B, mode, s, b, t)
             for b in range(B):
-                assert (res[mode][1][b] == res["0"][1][b]).all(), (B, mode, b)
+                assert (res[mode][1][b] == res[base][1][b]).all(), (B, mode, b)
 
 
 def test_activation_planes_follow_the_data_range(pkg, po, tmp_path):
@@ -229,7 +231,7 @@ def test_production_configuration_at_full_size_against_the_oracle(pkg, po, tmp_p
     eng.close()
 
 
-@pytest.mark.parametrize("B", [32, 48])
+@pytest.mark.parametrize("B", [32, 48, 64])
 def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path, B):
     """what `bench.py` times by default -- 32 (and 48) track lanes x the full 60 s segment
     (T = 2584) through lstm_batch2_kernel (groups of 16 lanes in turn: ring refills over 2,584 steps, 128-144 KB of LDS)
@@ -244,11 +246,12 @@ def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path
     tracks = [pkg.ggml.synth_audio(N, 410), pkg.ggml.synth_audio(N - 4321, 411)]
     which = [(i * 7 + i // 16) % 2 for i in range(B)]  # both tracks in every group of 16 lanes
     which[0], which[17] = 0, 1
-    checked = [0, 17] + ([40] if B > 32 else [])
+    checked = [0, 17] + ([40] if B > 32 else []) + ([55] if B > 48 else [])
     eng = pkg.Engine.from_file(path, N, tracks=B)
     assert eng.T == 2584 and eng.lstm_is_batched()
     got = eng.infer_batch([tracks[which[i]] for i in range(B)], pkg.FLAG_DEBUG_TAPS)
     assert eng.lstm_was_persistent()
+    assert eng.lstm_kernel_name() == ("lstm_batchs_kernel" if B <= 32 else "lstm_batcht_kernel")  # side by side; two such pairs in turn
     refs = []
     for k in range(2):
         st = po.stream_state(hidden)

@@ -146,7 +146,7 @@ CREATE_LSTM_BATCHED = 0x10
 CREATE_U8_DEQUANT = 0x20
 CREATE_GEMM_STAGED = 0x40
 CREATE_GEMM_PLANES = 0x80
-MAX_TRACKS = 48
+MAX_TRACKS = 64
 
 HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "umx_hip_n_tracks", "umx_hip_lstm_is_batched",
                "umx_hip_track_stream_reset", "umx_hip_track_stream_get", "umx_hip_track_stream_set",
@@ -204,7 +204,7 @@ class Engine:
         gemm: "planes" (fp16 matrix cores, operands pre-split into fp16 planes, LDS-DMA staging: the default with tracks > 1
         or lstm_batched) or "bf16x3" (bf16 terms, both operands split while every tile is staged: the default of the
         single-track engine); "f32" (the fp32-MFMA flavour of rounds 1-2) is refused;
-        tracks: independent track lanes (1..48) run together per call (infer_batch*);
+        tracks: independent track lanes (1..64) run together per call (infer_batch*);
         lstm_batched: use the batched (matrix-core) LSTM kernel also on a 1-track context."""
         self.lib = hip_lib()
         views, self._keep = views_from_file_tensors(targets, quantised)

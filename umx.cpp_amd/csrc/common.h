@@ -32,7 +32,7 @@ __host__ __device__ inline int round_up(int a, int b) { return (a + b - 1) / b *
 // call in one launch: a grid dimension runs over the entries of a LaneSet, and a lane's buffers sit a fixed stride apart
 // behind lane 0's (engine.hip allocates them that way).  One launch per kernel and call instead of one per lane: no
 // launch gaps and no partly filled last round of workgroups between the lanes (32 lanes: 192 -> 6 launches per call).
-constexpr int MAX_TRACK_LANES = 48; // = LSTMB_MAX_TRACKS (lstm_batch.h)
+constexpr int MAX_TRACK_LANES = 64; // = LSTMB_MAX_TRACKS (lstm_batch.h)
 struct LaneSet
 {
     int count;

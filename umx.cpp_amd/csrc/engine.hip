@@ -349,6 +349,14 @@ static const void *lstm_batchs_fn(int Hl, int groups, bool precise)
     default: return nullptr;
     }
 }
+static const void *lstm_batcht_fn(int Hl, bool precise) // 33 .. 64 lanes: two side-by-side pairs of groups in turn (lstm_batch.h)
+{
+    if (Hl == 512)
+        return precise ? reinterpret_cast<const void *>(lstm_batcht_kernel<512, true, 2>) : reinterpret_cast<const void *>(lstm_batcht_kernel<512, false, 2>);
+    if (Hl == 256)
+        return precise ? reinterpret_cast<const void *>(lstm_batcht_kernel<256, true, 2>) : reinterpret_cast<const void *>(lstm_batcht_kernel<256, false, 2>);
+    return nullptr;
+}
 constexpr int kBatchsBulk = 1, kBatchsSpan = 2; // ring rows per fetch (LDS: 128 KB of partial sums + 2 rows x 16 lanes x 528 B), slices per workgroup
 static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
 {
@@ -479,6 +487,7 @@ struct umx_hip_ctx
     // one segment of each of `nb` track lanes (lane i = track i of this context; audio[i] == nullptr: lane idle)
     int infer_batch(int nb, const float *const *audio_dev, const int *n, float *const *out /* [nb][4] */, unsigned flags);
     int lstm_batch_capacity = 0; // co-resident workgroups of the batched LSTM kernel
+    bool lstm_batcht_ok = false; // lstm_batcht_kernel (33 .. 64 lanes: two such pairs in turn) fits the chip
     bool lstm_batchs_ok = false; // lstm_batchs_kernel (two groups of 16 lanes side by side, 16 workgroups per chain) fits the chip
     bool lstm_rowsums = false;       // the batched recurrence hands the consuming plane GEMM the row sums of its output (lstm_batch.h, LstmBArgs::rs_dir)
     bool lstm_writes_planes = false; // ... and writes that GEMM's A planes itself (contexts of up to 32 lanes: lstm_batch_kernel / lstm_batchs_kernel)

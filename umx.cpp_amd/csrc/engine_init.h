@@ -37,7 +37,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
 {
     if (n_tracks < 1 || n_tracks > LSTMB_MAX_TRACKS)
     {
-        set_error("n_tracks must be in [1, 48]");
+        set_error("n_tracks must be in [1, 64]");
         return UMX_ERR_ARG;
     }
     B = n_tracks;
@@ -804,6 +804,26 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                         UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lg));
                         lstm_batchs_ok = lstm_batchs_ok && v >= 1 && 2 * 8 * (S / kBatchsSpan) <= v * cus;
                     }
+                }
+                // ... or, for 33 .. 64 lanes, two such pairs in turn through the same grid
+                lstm_batcht_ok = false;
+                if (B > 32 && lstm_batcht_fn(Hl, false) && S % kBatchsSpan == 0)
+                {
+                    const size_t lg = lstmb_lds_bytes(LSTMB_GROUP_TRACKS, kBatchsBulk, kBatchsSpan) + LSTMB_HSW_BYTES;
+                    lstm_batcht_ok = true;
+                    for (int precise = 0; precise < 2; ++precise)
+                    {
+                        const void *fn = lstm_batcht_fn(Hl, precise != 0);
+                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
+                        int v = 0;
+                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lg));
+                        lstm_batcht_ok = lstm_batcht_ok && v >= 1 && 2 * 8 * (S / kBatchsSpan) <= v * cus;
+                    }
+                }
+                if (B > 48 && !(lstm_batcht_ok && env_lstm_grouped))
+                {
+                    set_error("more than 48 track lanes need lstm_batcht_kernel (LSTM hidden 256 or 512, the grid co-resident, no UMX_LSTM_GROUPED=0)");
+                    return UMX_ERR_ARG;
                 }
             }
             lstm_batch_capacity = per_cu * cus;

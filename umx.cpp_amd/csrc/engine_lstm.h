@@ -165,16 +165,22 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     // 17 .. 32 lanes: the two groups side by side on the chip (lstm_batchs_kernel: half the hand-off bytes) where it fits, else -- and
     // for 33 .. 48 lanes -- the groups in turn through one twelve-wave workgroup (lstm_batch2.h).  Same bits either way.
     const bool grouped = groups == 2 && lstm_batchs_ok && env_lstm_grouped; // UMX_LSTM_GROUPED=0 (read at create): always the groups in turn
-    a.bulk = grouped ? kBatchsBulk : groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
-    const size_t lds = grouped ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) : groups > 1 ? lstmb2_lds_bytes(groups, a.bulk) : lstmb_lds_bytes(a.nbp, a.bulk);
-    const void *fn = grouped      ? lstm_batchs_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
+    // 33 .. 64 lanes: two such side-by-side pairs IN TURN through the same 256 workgroups (lstm_batcht_kernel, round 5); else lstm_batch2.h
+    const bool turned = groups >= 3 && groups <= 4 && lstm_batcht_ok && env_lstm_grouped;
+    a.bulk = (grouped || turned) ? kBatchsBulk : groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
+    const size_t lds = turned    ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) + LSTMB_HSW_BYTES // (the second turn's k-range sums of h')
+                       : grouped ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan)
+                       : groups > 1        ? lstmb2_lds_bytes(groups, a.bulk)
+                                           : lstmb_lds_bytes(a.nbp, a.bulk);
+    const void *fn = turned       ? lstm_batcht_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
+                     : grouped    ? lstm_batchs_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
                      : groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
                                   : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
-    lstm_kernel_last = grouped ? "lstm_batchs_kernel" : groups > 1 ? "lstm_batch2_kernel" : "lstm_batch_kernel";
-    const int threads = groups > 1 && !grouped ? LSTMB2_THREADS : LSTM_THREADS;
-    const int Sw = grouped ? groups * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
+    lstm_kernel_last = turned ? "lstm_batcht_kernel" : grouped ? "lstm_batchs_kernel" : groups > 1 ? "lstm_batch2_kernel" : "lstm_batch_kernel";
+    const int threads = groups > 1 && !grouped && !turned ? LSTMB2_THREADS : LSTM_THREADS;
+    const int Sw = (grouped || turned) ? 2 * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
     // the twelve-wave kernel of lstm_batch2.h takes the row sums but leaves the planes to split_planes_kernel
-    const bool writes_planes = fuse && lstm_writes_planes && (groups == 1 || grouped);
+    const bool writes_planes = fuse && lstm_writes_planes && (groups == 1 || grouped || turned);
     if (!writes_planes)
         for (int i = 0; i < 4; ++i)
             a.planes[i] = nullptr;
