@@ -323,6 +323,10 @@ const char *umx_hip_lstm_kernel_name(const umx_hip_ctx *ctx);
 int umx_hip_lstm_mode(umx_hip_ctx *ctx);
 /* UMX_FLAG_LSTM_PROFILE: shader-clock cycles summed over the T steps of each layer, for waves 0 and 1
  * of workgroup (chain 0, slice 0): out48[(layer*2 + wave)*8 + {0 poll, 1 dot, 2 barrier, 3 gates, 4 steps}] */
+/* Testing: the per-bin arithmetic both Wiener filter kernels share (|X|, PSDs with F5, Cxx with F6, closed-form inverse, y_j =
+ * v_j R_j (Cxx^-1 x) * max_abs; wiener.cpp:301-400) on caller-given bins: X [n][2][re, im], masks [n][4][2], R [n][4][R00, Re R01,
+ * Im R01, R11], y [n][4][2][re, im]; max_abs >= 1 (wiener.cpp:51).  Host pointers; needs a current HIP device. */
+int umx_hip_debug_wiener_bins(int n, const float *X, const float *masks, const float *R, float max_abs, float *y);
 int umx_hip_debug_lstm_profile(umx_hip_ctx *ctx, unsigned long long *out48);
 /* Where the workgroups of the last profiled one-track recurrence launch ran (UMX_FLAG_LSTM_PROFILE): out[i] for workgroup i =
  * XCC id << 48 | chain << 40 | slice << 32 | the 32-bit HW_ID register (CU, shader array, shader engine).  n <= 512. */

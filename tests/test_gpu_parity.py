@@ -336,6 +336,60 @@ def test_fused_wiener_istft_equals_the_unfused_kernels_bitwise(pkg, model_small,
             assert np.array_equal(res["fused"][1][t], res["stats4"][1][t])
 
 
+def test_wiener_bin_arithmetic_against_a_reference_order_float64_restatement(pkg):
+    """both filter kernels call wiener_bin_setup / wiener_bin_apply (csrc/wiener_kernels.h), so the fused-vs-unfused
+    test cannot see an error in that shared per-bin math, and since round 4 it forms y_j = v_j R_j (Cxx^-1 x) instead of the
+    reference's (v_j R_j Cxx^-1) x.  Here the device functions run on given bins (umx_hip_debug_wiener_bins) against numpy
+    float64 in the REFERENCE's operation order (wiener.cpp:187-202 PSD with F5, :301-325 Cxx with the 4x regularisation F6,
+    :54-84 inverse, :339-376 gain, :381-400 apply, :408-422 rescale): well-conditioned bins to 1e-5 of the bin's largest output, all-zero
+    masks (Cxx = 4 sqrt(eps) I, v = 0: exact zeros), a silent mixture bin (arg 0 = 0), and NaN in -> NaN out without touching its neighbours."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    n = 4096
+    X = (rng.standard_normal((n, 2, 2)) * rng.uniform(0.01, 30.0, (n, 1, 1))).astype(np.float32)
+    masks = rng.uniform(0.0, 1.5, (n, 4, 2)).astype(np.float32)
+    A = rng.standard_normal((n, 4, 2, 2)) + 1j * rng.standard_normal((n, 4, 2, 2))
+    Rm = A @ np.conj(np.swapaxes(A, -1, -2)) / 2 + 0.05 * np.eye(2)  # Hermitian positive definite, like sum y y^H / weight
+    R = np.stack([Rm[..., 0, 0].real, Rm[..., 0, 1].real, Rm[..., 0, 1].imag, Rm[..., 1, 1].real], axis=-1).astype(np.float32)
+    masks[0] = 0.0          # nothing of any source in this bin
+    X[1] = 0.0              # a silent mixture bin
+    X[2, 0, 0] = np.nan     # a poisoned bin
+    max_abs = np.float32(max(1.0, 30.0 / 10.0))
+    y = np.zeros((n, 4, 2, 2), np.float32)
+    fp = C.POINTER(C.c_float)
+    import torch
+    torch.zeros(1).cuda()  # a current device
+    rc = pkg.hip_lib().umx_hip_debug_wiener_bins(n, X.ctypes.data_as(fp), masks.ctypes.data_as(fp), R.ctypes.data_as(fp), C.c_float(float(max_abs)), y.ctypes.data_as(fp))
+    assert rc == 0
+    got = y[..., 0] + 1j * y[..., 1]  # (n, 4, 2)
+    # ---- float64, the reference's order, from the float32 inputs
+    Xc = X[..., 0].astype(np.float64) + 1j * X[..., 1].astype(np.float64)  # (n, 2)
+    mag = np.abs(Xc)
+    ph = np.where(mag > 0, Xc / np.where(mag > 0, mag, 1.0), 1.0)
+    Rd = R.astype(np.float64)
+    Rfull = np.empty((n, 4, 2, 2), np.complex128)
+    Rfull[..., 0, 0], Rfull[..., 1, 1] = Rd[..., 0], Rd[..., 3]
+    Rfull[..., 0, 1] = Rd[..., 1] + 1j * Rd[..., 2]
+    Rfull[..., 1, 0] = Rd[..., 1] - 1j * Rd[..., 2]
+    M = float(max_abs)
+    x = Xc / M
+    ys = (masks.astype(np.float64) * mag[:, None, :]) * ph[:, None, :] / M  # (n, 4, 2): polar(mag_j, arg X) / max_abs
+    v = 0.5 * ((ys.real + ys.imag) ** 2).sum(axis=-1)  # F5
+    Cxx = (np.sqrt(1e-10) * np.eye(2)[None, None] + v[..., None, None] * Rfull).sum(axis=1)  # F6: once per source
+    inv = np.linalg.inv(np.where(np.isfinite(Cxx), Cxx, np.eye(2)))
+    G = v[..., None, None] * (Rfull @ inv[:, None])  # wiener.cpp:339-376
+    ref = np.einsum("nsab,nb->nsa", G, x) * M
+    ok = np.isfinite(Xc).all(axis=-1)
+    scale = np.abs(ref[ok]).max(axis=(1, 2), keepdims=True) + 1e-30
+    err = np.abs(got[ok] - ref[ok]) / scale
+    worst = float(err[3:].max())
+    assert worst < 1e-5, worst  # measured ~2e-6: fp32 evaluation of a 2 x 2 solve with condition numbers up to ~1e2
+    assert (got[0] == 0).all()                       # v = 0: exact zeros
+    assert (got[1] == 0).all() or float(np.abs(got[1]).max()) == 0.0  # x = 0
+    assert not np.isfinite(got[2]).all()             # NaN in -> NaN out
+    assert np.isfinite(got[3:]).all()
+
+
 def test_gemm_flavours_agree(pkg, po, model_small, tmp_path):
     """The dense stack runs on the 16-bit matrix cores with split operands and fp32 accumulation: gemm="bf16x3" splits into
     three bf16 terms while it stages every tile (csrc/gemm_bf16x3.h, the single-track default), gemm="planes" consumes

@@ -121,6 +121,7 @@ def hip_lib():
     lib.umx_hip_lstm_was_persistent.argtypes = [C.c_void_p]
     lib.umx_hip_lstm_mode.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.umx_hip_debug_wiener_bins.argtypes = [C.c_int, _fp, _fp, _fp, C.c_float, _fp]
     lib.umx_hip_lstm_kernel_name.restype = C.c_char_p
     lib.umx_hip_lstm_kernel_name.argtypes = [C.c_void_p]
     lib.umx_hip_debug_lstm_placement.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
@@ -158,7 +159,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
                "umx_hip_stage_times_slot", "umx_hip_stage_kernel_times_slot",
-               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_lstm_kernel_name", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
+               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_lstm_kernel_name", "umx_hip_debug_wiener_bins", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
                "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits",

@@ -218,6 +218,57 @@ int umx_hip_shift_inference(umx_hip_ctx *ctx, const float *audio_host, int lengt
     return ctx->track(audio_host, length, offset, out_host, flags, progress, progress_user);
 }
 
+// testing: the per-bin arithmetic of the Wiener filter -- mix_magnitude, wiener_bin_setup, wiener_bin_apply, the
+// functions BOTH filter kernels call -- on caller-given bins, so that a test can hold it against an independent float64
+// restatement of wiener.cpp:301-400 in the reference's own operation order (the fused-vs-unfused test compares two callers of
+// the same functions).  X [n][2 channels][re, im], masks [n][4 sources][2 channels], R [n][4][R00, Re R01, Im R01, R11],
+// y out [n][4][2][re, im].  Needs a current device; no context.
+__global__ void debug_wiener_bins_kernel(int n, const float *X, const float *masks, const float *R, float max_abs, float *y)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n)
+        return;
+    const float2 X0 = make_float2(X[b * 4 + 0], X[b * 4 + 1]), X1 = make_float2(X[b * 4 + 2], X[b * 4 + 3]);
+    const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
+    float m0[4], m1[4];
+    float4 rc[4];
+    for (int s = 0; s < 4; ++s)
+    {
+        m0[s] = masks[(b * 4 + s) * 2 + 0] * h0; // inference.cpp:175-183
+        m1[s] = masks[(b * 4 + s) * 2 + 1] * h1;
+        rc[s] = make_float4(R[(b * 4 + s) * 4 + 0], R[(b * 4 + s) * 4 + 1], R[(b * 4 + s) * 4 + 2], R[(b * 4 + s) * 4 + 3]);
+    }
+    WienerBin wb;
+    wiener_bin_setup(X0, X1, m0, m1, rc, max_abs, 1.0f / max_abs, wb);
+    for (int s = 0; s < 4; ++s)
+    {
+        float2 o[2];
+        wiener_bin_apply(wb, s, rc[s], max_abs, o);
+        y[((b * 4 + s) * 2 + 0) * 2 + 0] = o[0].x;
+        y[((b * 4 + s) * 2 + 0) * 2 + 1] = o[0].y;
+        y[((b * 4 + s) * 2 + 1) * 2 + 0] = o[1].x;
+        y[((b * 4 + s) * 2 + 1) * 2 + 1] = o[1].y;
+    }
+}
+int umx_hip_debug_wiener_bins(int n, const float *X, const float *masks, const float *R, float max_abs, float *y)
+{
+    if (n < 1 || !X || !masks || !R || !y || !(max_abs >= 1.0f))
+        return UMX_ERR_ARG;
+    float *d = nullptr;
+    const size_t nx = (size_t)n * 4, nm = (size_t)n * 8, nr = (size_t)n * 16, ny = (size_t)n * 16;
+    if (hipMalloc(reinterpret_cast<void **>(&d), (nx + nm + nr + ny) * sizeof(float)) != hipSuccess)
+        return UMX_ERR_HIP;
+    bool ok = hipMemcpy(d, X, nx * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d + nx, masks, nm * 4, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d + nx + nm, R, nr * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok)
+    {
+        hipLaunchKernelGGL(debug_wiener_bins_kernel, dim3((n + 63) / 64), dim3(64), 0, nullptr, n, d, d + nx, d + nx + nm, max_abs, d + nx + nm + nr);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(y, d + nx + nm + nr, ny * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    return ok ? UMX_OK : UMX_ERR_HIP;
+}
+
 // debugging: queue `launches` LDS-guard kernels on a private stream (they run beside whatever the caller
 // queues next); read the counters back with launches == 0 (returns words corrupted, events in out2[0..1])
 int umx_hip_debug_lds_guard(umx_hip_ctx *ctx, int launches, int rounds, unsigned *out2)
