@@ -311,7 +311,7 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr unsigned LSTM_SPIN_LIMIT = 1u << 22; // bounded spins: ~seconds, then abort the launch
-#define LSTM_POLLS_IN_FLIGHT 1 // measured best once two LSTM grids share the chip (2: -3 %, 3: -5 %)
+#define LSTM_POLLS_IN_FLIGHT 1 // measured best alone and with two grids on the chip (round 5, alone: 2: +3 %, 3: +10 %; round 1, pipelined: 2: +3 %, 3: +5 %)
 #define LSTM_TRACE_SLICE 5
 #define LSTM_TRACE_STEP0 1200
 #define LSTM_PROF_WAVE 1 // the dot wave the in-kernel profiler reports beside the gate wave
