@@ -528,7 +528,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
     // cycles; beside a GEMM or a streaming kernel of the other pipeline slot it is several microseconds, and a
     // row fetched every step put exactly that in front of every step (an LSTM launch sharing the chip with a
     // copy kernel ran 3x slower).  So rows are fetched in bulk, LSTM_P_BULK at a time and LSTM_P_BULK..2x steps
-    // ahead, straight into an LDS ring (global_load_lds: no VGPRs, no ds_write), two rows per dot wave: the
+    // ahead, straight into an LDS ring (global_load_lds: no VGPRs, no ds_write), by waves 1..7 at the top of a step: the
     // loaded-latency is paid once per LSTM_P_BULK steps instead of once per step.
     typedef __attribute__((address_space(3))) void *lds_ptr;
     typedef const __attribute__((address_space(1))) void *glb_ptr;
@@ -642,8 +642,7 @@ __device__ __forceinline__ void lstm_persistent_body(const LstmArgs &a, int chai
                 // 16 in-row rotations x 4 columns, 4 independent accumulators
                 float acc[4] = {0.f, 0.f, 0.f, 0.f};
                 DotDpp<15>::run(Wd, __float_as_int(hval), acc);
-                // rows r and r+2 meet through v_permlane32_swap (lanes l <-> l+32), rows r and r^1 through a
-                // 16-lane swizzle: lane rows {0,1} end with gates 0 and 2, rows {2,3} with gates 1 and 3
+                // rows r and r+2 meet through v_permlane32_swap (lanes l <-> l+32): lane rows {0,1} then hold gates 0 and 2, rows {2,3} gates 1 and 3
                 float s0, s1;
                 {
                     const auto r01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[1]), false, false);
