@@ -26,6 +26,19 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
+// the transform's own twiddle products (not the reference's arithmetic: its FFT is kissfft): two multiplies and two fused multiply-adds
+// instead of four multiplies, an add and a subtract -- the engine is built with -ffp-contract=off, so the fusion is spelled out
+#ifndef FFT_CMUL_FMA
+#define FFT_CMUL_FMA 1
+#endif
+__device__ __forceinline__ float2 cmul_tw(float2 a, float2 b)
+{
+#if FFT_CMUL_FMA
+    return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+#else
+    return cmul(a, b);
+#endif
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
@@ -59,15 +72,15 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16])
     const float2 w1 = make_float2(C1, SG * S1), w2 = make_float2(R2, SG * R2),
                  w3 = make_float2(S1, SG * C1), w6 = make_float2(-R2, SG * R2),
                  w9 = make_float2(-C1, -SG * S1);
-    a[1][1] = cmul(a[1][1], w1);
-    a[1][2] = cmul(a[1][2], w2);
-    a[1][3] = cmul(a[1][3], w3);
-    a[2][1] = cmul(a[2][1], w2);
+    a[1][1] = cmul_tw(a[1][1], w1);
+    a[1][2] = cmul_tw(a[1][2], w2);
+    a[1][3] = cmul_tw(a[1][3], w3);
+    a[2][1] = cmul_tw(a[2][1], w2);
     a[2][2] = mul_w4<INV>(a[2][2]); // W16^4
-    a[2][3] = cmul(a[2][3], w6);
-    a[3][1] = cmul(a[3][1], w3);
-    a[3][2] = cmul(a[3][2], w6);
-    a[3][3] = cmul(a[3][3], w9);
+    a[2][3] = cmul_tw(a[2][3], w6);
+    a[3][1] = cmul_tw(a[3][1], w3);
+    a[3][2] = cmul_tw(a[3][2], w6);
+    a[3][3] = cmul_tw(a[3][3], w9);
 #pragma unroll
     for (int q0 = 0; q0 < 4; ++q0)
     {
@@ -107,7 +120,7 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const floa
         for (int r = 1; r < 16; ++r)
         {
             float2 w = tw1[r * 16 + k];
-            v[r] = cmul(v[r], INV ? cconj(w) : w);
+            v[r] = cmul_tw(v[r], INV ? cconj(w) : w);
         }
         fft16<INV>(v);
         const int base = ((j - k) << 4) + k;
@@ -125,7 +138,7 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const floa
         for (int r = 1; r < 16; ++r)
         {
             float2 w = tw2[r * 256 + j];
-            v[r] = cmul(v[r], INV ? cconj(w) : w);
+            v[r] = cmul_tw(v[r], INV ? cconj(w) : w);
         }
         fft16<INV>(v);
 #pragma unroll
