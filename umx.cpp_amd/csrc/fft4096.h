@@ -28,16 +28,9 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 }
 // the transform's own twiddle products (not the reference's arithmetic: its FFT is kissfft): two multiplies and two fused multiply-adds
 // instead of four multiplies, an add and a subtract -- the engine is built with -ffp-contract=off, so the fusion is spelled out
-#ifndef FFT_CMUL_FMA
-#define FFT_CMUL_FMA 1
-#endif
 __device__ __forceinline__ float2 cmul_tw(float2 a, float2 b)
 {
-#if FFT_CMUL_FMA
     return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
-#else
-    return cmul(a, b);
-#endif
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
