@@ -205,6 +205,18 @@ def test_hot_kernels_keep_their_register_budgets(device_asm):
     # two groups of 16 lanes side by side, chains of 16 workgroups with two slices each (one workgroup per CU): nothing spilled
     vg, sp = find("lstm_batchs_kernelILi512ELb0ELi2E")
     assert vg <= 256 and sp == 0, (vg, sp)
+    # octets of 8 lanes x column shards of 64 units (round 5): 128 registers of W_hh fragments per wave; the PROLOGUE (256 byte loads per
+    # lane into those fragments) spills, the step loop must not: no scratch access behind the first loop header of the step loop
+    vg, sp = find("lstm_batch8_kernelILi512ELb0E")
+    assert vg <= 256 and sp <= 96, (vg, sp)
+    body = device_asm[device_asm.index("_ZN3umx18lstm_batch8_kernelILi512ELb0EEEvNS_9LstmBArgsE:"):]
+    body = body[:body.index(".Lfunc_end")]
+    steps = body.split("=>This Loop Header: Depth=1")[1:]  # (the two step loops: intra-XCD and sc1 protocol; "Inner Loop Header" = the others)
+    assert len(steps) == 2, len(steps)
+    for seg in steps:
+        assert "v_mfma_f32_16x16x32_f16" in seg
+        loop = seg[:seg.index("buffer_store_dwordx4")]  # through the granule publication at the end of the gate phase
+        assert "scratch_" not in loop, "the step loop of lstm_batch8_kernel touches scratch"
     # fused Wiener / inverse STFT / overlap-add: 1024 threads = at most 128
     vg, sp = find("wiener_istft_kernelILb1EE")
     assert vg <= 128 and sp == 0, (vg, sp)

@@ -153,6 +153,9 @@ def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, 
     H, N = 1024, 40 * 1024
     path = str(tmp_path / "m.bin")
     pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=53), H, compress=False)
+    # (hidden 1024 runs csrc/lstm_batch8.h by default since the end of round 5 -- other sums, its own tests below; the kernels compared
+    # here remain for the other hidden sizes and behind this switch)
+    monkeypatch.setenv("UMX_LSTM8_MIN_LANES", "99")
     for B in (20, 32, 40, 64):  # 40, 64 (round 5): lstm_batcht_kernel, two such pairs in turn, against lstm_batch2.h's three groups in turn
         waves = [[pkg.ggml.synth_audio(N - 97 * b, 2300 + 10 * b + s) for b in range(B)] for s in range(2)]
         res = {}
@@ -251,7 +254,7 @@ def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path
     assert eng.T == 2584 and eng.lstm_is_batched()
     got = eng.infer_batch([tracks[which[i]] for i in range(B)], pkg.FLAG_DEBUG_TAPS)
     assert eng.lstm_was_persistent()
-    assert eng.lstm_kernel_name() == ("lstm_batchs_kernel" if B <= 32 else "lstm_batcht_kernel")  # side by side; two such pairs in turn
+    assert eng.lstm_kernel_name() == "lstm_batch8_kernel"  # octets of 8 lanes x column shards of 64 units (more than 32 lanes: two launches per layer)
     refs = []
     for k in range(2):
         st = po.stream_state(hidden)

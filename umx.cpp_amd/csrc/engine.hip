@@ -30,6 +30,7 @@
 #include "lstm_kernels.h"
 #include "lstm_batch.h"
 #include "lstm_batch2.h"
+#include "lstm_batch8.h"
 #include "track_kernels.h"
 #include "stft_kernels.h"
 #include "wiener_kernels.h"
@@ -357,6 +358,13 @@ static const void *lstm_batcht_fn(int Hl, bool precise) // 33 .. 64 lanes: two s
         return precise ? reinterpret_cast<const void *>(lstm_batcht_kernel<256, true, 2>) : reinterpret_cast<const void *>(lstm_batcht_kernel<256, false, 2>);
     return nullptr;
 }
+// octets of 8 lanes x column shards of 64 units (lstm_batch8.h): hidden 512, u8-resident W_hh
+static const void *lstm_batch8_fn(int Hl, bool precise)
+{
+    if (Hl == 512)
+        return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<512, true>) : reinterpret_cast<const void *>(lstm_batch8_kernel<512, false>);
+    return nullptr;
+}
 constexpr int kBatchsBulk = 1, kBatchsSpan = 2; // ring rows per fetch (LDS: 128 KB of partial sums + 2 rows x 16 lanes x 528 B), slices per workgroup
 static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
 {
@@ -487,6 +495,9 @@ struct umx_hip_ctx
     // one segment of each of `nb` track lanes (lane i = track i of this context; audio[i] == nullptr: lane idle)
     int infer_batch(int nb, const float *const *audio_dev, const int *n, float *const *out /* [nb][4] */, unsigned flags);
     int lstm_batch_capacity = 0; // co-resident workgroups of the batched LSTM kernel
+    bool lstm_batch8_ok = false; // lstm_batch8_kernel (octets of 8 lanes, lstm_batch8.h) serves this context's batched launches
+    int lstm8_poll_delay = 0;    // UMX_LSTM8_POLL_DELAY (read at create)
+    int env_lstm8_min = 1;       // UMX_LSTM8_MIN_LANES (read at create): contexts of at least this many lanes use it (99: none)
     bool lstm_batcht_ok = false; // lstm_batcht_kernel (33 .. 64 lanes: two such pairs in turn) fits the chip
     bool lstm_batchs_ok = false; // lstm_batchs_kernel (two groups of 16 lanes side by side, 16 workgroups per chain) fits the chip
     bool lstm_rowsums = false;       // the batched recurrence hands the consuming plane GEMM the row sums of its output (lstm_batch.h, LstmBArgs::rs_dir)

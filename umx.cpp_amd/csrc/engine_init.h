@@ -168,6 +168,10 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         env_lstm_grouped = atoi(e) != 0;
     if (const char *e = getenv("UMX_GEMM_PP"))
         env_gemm_pp = atoi(e);
+    if (const char *e = getenv("UMX_LSTM8_POLL_DELAY")) // tuning: x64 cycles between a wave's publication and its first poll (lstm_batch8.h)
+        lstm8_poll_delay = atoi(e);
+    if (const char *e = getenv("UMX_LSTM8_MIN_LANES")) // contexts of this many lanes or more (up to 32) run lstm_batch8_kernel; 99: never
+        env_lstm8_min = atoi(e);
     if (const char *e = getenv("UMX_LSTM_POLL_DELAY")) // tuning: x64 cycles a dot wave of the one-track recurrence sleeps before its first poll
         lstm_poll_delay = atoi(e);
     wiener_fused = lstm_batched;
@@ -826,6 +830,21 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                     return UMX_ERR_ARG;
                 }
             }
+            // octets of 8 lanes x column shards of 64 units (lstm_batch8.h): chosen by the CONTEXT's lane count, for every launch of the
+            // context -- its sums are not the bits of the kernels above, and a lane's result must not depend on who rides along
+            lstm_batch8_ok = false;
+            if (env_lstm_grouped && B >= env_lstm8_min && B <= 2 * LSTM8_OCTETS * LSTM8_TRACKS && lstm_batch8_fn(Hl, false) && S == 32 && !u8_dequant && whh_q[0] && whh_q[1] && whh_q[2])
+            {
+                lstm_batch8_ok = true;
+                for (int precise = 0; precise < 2; ++precise)
+                {
+                    const void *fn = lstm_batch8_fn(Hl, precise != 0);
+                    UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm8_lds_bytes(Hl)));
+                    int v = 0;
+                    UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstm8_lds_bytes(Hl)));
+                    lstm_batch8_ok = lstm_batch8_ok && v >= 1 && 8 * 32 <= v * cus;
+                }
+            }
             lstm_batch_capacity = per_cu * cus;
             // the recurrence writes the plane GEMMs' A operands (layers 1, 2 and fc2's right half) and their row sums itself where
             // it runs on the u8-resident W_hh (its gate lanes hold h as two fp16 planes, its all-ones tile the row sums): no
@@ -833,7 +852,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
             // More than 32 lanes (lstm_batch2.h, no register left): only the row sums; split_planes_kernel still writes the planes -- the
             // same bits, so a track's result does not depend on the size of the context.
             lstm_rowsums = UMX_FUSE_LSTM_PLANES && gemm_planes && !u8_dequant && whh_q[0] && whh_q[1] && whh_q[2];
-            lstm_writes_planes = lstm_rowsums && B <= 2 * LSTMB_GROUP_TRACKS;
+            lstm_writes_planes = lstm_rowsums && (B <= 2 * LSTMB_GROUP_TRACKS || lstm_batch8_ok);
         }
     }
     // dynamic LDS > 64 KiB must be opted into

@@ -139,6 +139,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     }
     a.nchains = 2 * nact;
     a.lane_mask = lane_mask;
+    a.poll_delay = lstm8_poll_delay;
     const bool wq_layer = whh_q[layer] != nullptr && !u8_dequant;
     const bool fuse = lstm_rowsums && wq_layer;
     if (fuse)
@@ -164,23 +165,26 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     const bool wq = whh_q[layer] != nullptr && !u8_dequant;
     // 17 .. 32 lanes: the two groups side by side on the chip (lstm_batchs_kernel: half the hand-off bytes) where it fits, else -- and
     // for 33 .. 48 lanes -- the groups in turn through one twelve-wave workgroup (lstm_batch2.h).  Same bits either way.
-    const bool grouped = groups == 2 && lstm_batchs_ok && env_lstm_grouped; // UMX_LSTM_GROUPED=0 (read at create): always the groups in turn
+    const bool octets = lstm_batch8_ok; // lstm_batch8.h: every launch of this context, whatever lanes take part
+    const bool grouped = !octets && groups == 2 && lstm_batchs_ok && env_lstm_grouped; // UMX_LSTM_GROUPED=0 (read at create): always the groups in turn
     // 33 .. 64 lanes: two such side-by-side pairs IN TURN through the same 256 workgroups (lstm_batcht_kernel, round 5); else lstm_batch2.h
-    const bool turned = groups >= 3 && groups <= 4 && lstm_batcht_ok && env_lstm_grouped;
+    const bool turned = !octets && groups >= 3 && groups <= 4 && lstm_batcht_ok && env_lstm_grouped;
     a.bulk = (grouped || turned) ? kBatchsBulk : groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
-    const size_t lds = turned    ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) + LSTMB_HSW_BYTES // (the second turn's k-range sums of h')
+    const size_t lds = octets    ? lstm8_lds_bytes(Hl)
+                       : turned  ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) + LSTMB_HSW_BYTES // (the second turn's k-range sums of h')
                        : grouped ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan)
                        : groups > 1        ? lstmb2_lds_bytes(groups, a.bulk)
                                            : lstmb_lds_bytes(a.nbp, a.bulk);
-    const void *fn = turned       ? lstm_batcht_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
+    const void *fn = octets       ? lstm_batch8_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
+                     : turned     ? lstm_batcht_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
                      : grouped    ? lstm_batchs_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
                      : groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
                                   : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
-    lstm_kernel_last = turned ? "lstm_batcht_kernel" : grouped ? "lstm_batchs_kernel" : groups > 1 ? "lstm_batch2_kernel" : "lstm_batch_kernel";
-    const int threads = groups > 1 && !grouped && !turned ? LSTMB2_THREADS : LSTM_THREADS;
-    const int Sw = (grouped || turned) ? 2 * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
+    lstm_kernel_last = octets ? "lstm_batch8_kernel" : turned ? "lstm_batcht_kernel" : grouped ? "lstm_batchs_kernel" : groups > 1 ? "lstm_batch2_kernel" : "lstm_batch_kernel";
+    const int threads = groups > 1 && !grouped && !turned && !octets ? LSTMB2_THREADS : LSTM_THREADS;
+    const int Sw = octets ? 32 : (grouped || turned) ? 2 * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
     // the twelve-wave kernel of lstm_batch2.h takes the row sums but leaves the planes to split_planes_kernel
-    const bool writes_planes = fuse && lstm_writes_planes && (groups == 1 || grouped || turned);
+    const bool writes_planes = fuse && lstm_writes_planes && (groups == 1 || grouped || turned || octets);
     if (!writes_planes)
         for (int i = 0; i < 4; ++i)
             a.planes[i] = nullptr;
@@ -188,9 +192,15 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     sl.lstm_wrote_planes[layer] = writes_planes;
     sl.lstm_rows_f32[layer] = !writes_planes || a.write_f32;
     void *kargs[] = {&a};
+    // lstm_batch8.h serves 32 lanes per launch: a context of 33 .. 64 lanes runs its two halves one after the other
+    const int halves = octets && top > LSTM8_OCTETS * LSTM8_TRACKS ? 2 : 1;
+    auto half_on = [&](int hf) { return halves == 1 || ((lane_mask >> (32 * hf)) & 0xffffffffull) != 0; };
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
-    if (persistent)
+    for (int hf = 0; persistent && hf < halves; ++hf)
     {
+        if (!half_on(hf))
+            continue;
+        a.lane_base = 32 * hf;
         a.tag_epoch = next_tag_base() >> 12; // unique per launch (20 bits); the granule area is cleared when it wraps
         const bool clear = tag_epoch == 0;
         a.t_begin = 0;
@@ -204,7 +214,7 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         {
             (void)hipGetLastError();
             persistent_ok = false;
-            persistent = false;
+            persistent = false; // (nothing of this layer has run: the first half's launch is the one that can be refused)
         }
     }
     if (!persistent)
@@ -224,7 +234,12 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
             a.t_end = step + 1;
             a.state = (step & 1) ? state_alt : state;
             a.state_out = (step & 1) ? state : state_alt;
-            UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * Sw), dim3(threads), kargs, lds, st));
+            for (int hf = 0; hf < halves; ++hf)
+                if (half_on(hf))
+                {
+                    a.lane_base = 32 * hf;
+                    UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * Sw), dim3(threads), kargs, lds, st));
+                }
         }
         if (T & 1) // the last launch wrote state_alt
             UMX_HIP_CHECK(hipMemcpy2DAsync(state + off, pitch, state_alt + off, pitch, row, (size_t)4 * B, hipMemcpyDeviceToDevice, st));

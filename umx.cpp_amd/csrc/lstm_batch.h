@@ -90,6 +90,8 @@ struct LstmBArgs
     size_t rs_rows;
     int ldpl, Tp;
     int write_f32;             // with planes: also keep the fp32 rows of every step (debug taps); without planes they always are
+    int lane_base;             // lstm_batch8.h: the launch serves track lanes [lane_base, lane_base + 32)
+    int poll_delay;            // lstm_batch8.h: x64 cycles a wave sleeps between its publication and its first poll of the next step
 };
 
 __host__ __device__ inline size_t lstmb_granule_words(int Hl) { return (size_t)2 * 8 * Hl * 16 * 2; } // 32-bit words
