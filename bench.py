@@ -5,8 +5,8 @@ A "step" = one pass of the hot path (umx_inference, inference.cpp:12-207) over o
 EVERY track lane of the context: STFT -> 4 x [fc1/bn/tanh -> 3-layer BiLSTM -> fc2 -> fc3 -> mask] -> Wiener EM ->
 4 x iSTFT.  Consecutive steps are consecutive segments of the same tracks: the streaming LSTM state carries over
 (umx.cpp:167-171).  The default workload is BASELINE config 3 (4 stems + Wiener, the full umx_inference) on
---tracks independent tracks per GPU (default 32: their LSTM recurrences share one matrix-core launch per layer,
-SURVEY 8f-4); --tracks 1 is the single-track, latency-optimised engine; --no-wiener gives config 2, --vocals-only
+--tracks independent tracks per GPU (default 64: their LSTM recurrences share one matrix-core launch per layer,
+SURVEY 8f-4; ~180 GB of the 288 GB of HBM); --tracks 1 is the single-track, latency-optimised engine; --no-wiener gives config 2, --vocals-only
 config 1.
 
 What the JSON line holds (one line, rank 0):
@@ -20,7 +20,7 @@ What the JSON line holds (one line, rank 0):
                                (lone_segment_ms_latency_context: the same in a one-track context created with UMX_CREATE_GEMM_PLANES)
   checked_max_abs  after the timed region: two lanes of the batched engine, from a reset state, against the single-track
                    engine on the same audio (max |difference| over the stems; `outputs_checked` = below 1e-5).  The
-                   oracle comparison of this configuration is tests/test_gpu_batch.py (full size, 32 and 48 lanes).
+                   oracle comparison of this configuration is tests/test_gpu_batch.py (full size, 32, 48 and 64 lanes).
   single_track     details of the --tracks 1 engine on the same GPU
   roofline         the dominant kernel by device time: live HIP-event duration per launch (events on the engine's own
                    streams); `achieved` / `frac` = ALGORITHMIC flops per launch / duration / peak of the
@@ -131,10 +131,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--tracks", type=int, default=32,
+    ap.add_argument("--tracks", type=int, default=64,
                     help="independent tracks per GPU run together (track lanes, 1..64): one step = one 60 s segment of EVERY "
-                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4), > 16 its form that takes groups "
-                         "of 16 lanes side by side (17-32: lstm_batchs_kernel), > 32 two such pairs in turn (lstm_batcht_kernel)")
+                         "track; > 1 selects the batched matrix-core LSTM kernel (SURVEY 8f-4): workgroups of 8 lanes x 64 hidden "
+                         "units (lstm_batch8_kernel), > 32 two such octets per workgroup in turn")
     ap.add_argument("--batched-lstm", action="store_true", help="use the batched LSTM kernel also with --tracks 1")
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--segment-samples", type=int, default=SEG)
@@ -463,6 +463,10 @@ def main():
             lp = 2 if (not args.expanded_weights and not args.u8_dequant) else 6  # u8 W_hh: 1 fp16 plane x 2 fp16 planes of h
             groups = (B + 15) // 16  # the matrix instruction is 16 tracks wide: one MFMA phase per group of 16 lanes
             lstm_issued = rec * 16 * groups * lp * (1.25 if lp == 2 else 1.0)  # + the all-ones tile of the u8 form
+            if lstm_kernel == "lstm_batch8_kernel":
+                # csrc/lstm_batch8.h: N = 16 = an octet of 8 lanes x the 2 planes of h; 34 matrix instructions per wave and step of which 2
+                # are the all-ones tile's
+                lstm_issued = rec * 8 * ((B + 7) // 8) * 2 * (34.0 / 32.0)
             lname = lstm_kernel
         else:
             lstm_issued = lstm_alg
@@ -558,7 +562,9 @@ def main():
                                     "seeded synthetic 44.1 kHz stereo, synthetic UMX-L-shaped u8/u16 ggml weights"),
                        "hidden": H, "segment_samples": N, "frames": T, "stems": 4, "tracks_per_gpu": B,
                        "audio_seconds_per_step": B * seg_sec,
-                       "lstm_kernel": ({"lstm_batcht_kernel": "batched, matrix cores, two side-by-side pairs of 16-lane groups in turn (lstm_batcht_kernel)",
+                       "lstm_kernel": ({"lstm_batch8_kernel": "batched, matrix cores, workgroups of 8 lanes x 64 hidden units" +
+                                                              (", two octets per workgroup in turn" if B > 32 else "") + " (lstm_batch8_kernel)",
+                                        "lstm_batcht_kernel": "batched, matrix cores, two side-by-side pairs of 16-lane groups in turn (lstm_batcht_kernel)",
                                         "lstm_batch2_kernel": "batched, matrix cores, groups of 16 lanes in turn (lstm_batch2_kernel)",
                                         "lstm_batchs_kernel": "batched, matrix cores, two groups of 16 lanes side by side (lstm_batchs_kernel)",
                                         "lstm_batch_kernel": "batched, matrix cores (lstm_batch_kernel)"}.get(lstm_kernel, lstm_kernel)

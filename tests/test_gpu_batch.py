@@ -179,6 +179,37 @@ def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, 
                 assert (res[mode][1][b] == res[base][1][b]).all(), (B, mode, b)
 
 
+def test_two_octets_in_turn_give_the_bits_of_two_launches(pkg, tmp_path, monkeypatch):
+    """33 .. 64 lanes, hidden 1024: csrc/lstm_batch8.h with two octets per workgroup IN TURN (one launch per layer; the polls of one
+    octet travel under the matrix and gate phases of the other) against the same kernel with one octet per workgroup, the two halves
+    of the context one launch after the other (UMX_LSTM8_PAIRED=0), and against the per-step driver: per (unit, lane) the arithmetic
+    does not know about turns, so stems and carried state agree bit for bit -- 40 lanes (workgroups with one octet and with two), 64
+    lanes, ragged lengths, two segments."""
+    H, N = 1024, 40 * 1024
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=57), H, compress=False)
+    for B in (40, 64):
+        waves = [[pkg.ggml.synth_audio(N - 97 * b, 3300 + 10 * b + s) for b in range(B)] for s in range(2)]
+        res = {}
+        for mode in ("halves", "paired", "stepwise"):
+            if mode == "halves":
+                monkeypatch.setenv("UMX_LSTM8_PAIRED", "0")
+            else:
+                monkeypatch.delenv("UMX_LSTM8_PAIRED", raising=False)
+            eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
+            outs = [eng.infer_batch(w, pkg.FLAG_LSTM_STEPWISE if mode == "stepwise" else 0) for w in waves]
+            assert eng.lstm_kernel_name() == "lstm_batch8_kernel"
+            res[mode] = (outs, [eng.track_stream_get(b) for b in range(B)])
+            eng.close()
+        for mode in ("paired", "stepwise"):
+            for s in range(2):
+                for b in range(B):
+                    for t in range(4):
+                        assert (res[mode][0][s][b][t] == res["halves"][0][s][b][t]).all(), (B, mode, s, b, t)
+            for b in range(B):
+                assert (res[mode][1][b] == res["halves"][1][b]).all(), (B, mode, b)
+
+
 def test_activation_planes_follow_the_data_range(pkg, po, tmp_path):
     """The plane GEMMs take every activation row as two fp16 planes of the row scaled by a power of two (csrc/gemm_planes.h):
     the scale follows the row, so a near-silent track (1e-5 of full scale, where a fixed-range fp16 split would be all

@@ -359,11 +359,13 @@ static const void *lstm_batcht_fn(int Hl, bool precise) // 33 .. 64 lanes: two s
     return nullptr;
 }
 // octets of 8 lanes x column shards of 64 units (lstm_batch8.h): hidden 512, u8-resident W_hh
-static const void *lstm_batch8_fn(int Hl, bool precise)
+static const void *lstm_batch8_fn(int Hl, bool precise, int no = 1) // no = 2: two octets per workgroup in turn (33 .. 64 lanes in one launch)
 {
-    if (Hl == 512)
-        return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<512, true>) : reinterpret_cast<const void *>(lstm_batch8_kernel<512, false>);
-    return nullptr;
+    if (Hl != 512)
+        return nullptr;
+    if (no == 2)
+        return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<512, true, 2>) : reinterpret_cast<const void *>(lstm_batch8_kernel<512, false, 2>);
+    return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<512, true, 1>) : reinterpret_cast<const void *>(lstm_batch8_kernel<512, false, 1>);
 }
 constexpr int kBatchsBulk = 1, kBatchsSpan = 2; // ring rows per fetch (LDS: 128 KB of partial sums + 2 rows x 16 lanes x 528 B), slices per workgroup
 static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
@@ -497,6 +499,7 @@ struct umx_hip_ctx
     int lstm_batch_capacity = 0; // co-resident workgroups of the batched LSTM kernel
     bool lstm_batch8_ok = false; // lstm_batch8_kernel (octets of 8 lanes, lstm_batch8.h) serves this context's batched launches
     int lstm8_poll_delay = 0;    // UMX_LSTM8_POLL_DELAY (read at create)
+    bool env_lstm8_paired = true; // UMX_LSTM8_PAIRED=0 (read at create): 33 .. 64 lanes as two launches of 32 instead of two octets per workgroup in turn
     int env_lstm8_min = 1;       // UMX_LSTM8_MIN_LANES (read at create): contexts of at least this many lanes use it (99: none)
     bool lstm_batcht_ok = false; // lstm_batcht_kernel (33 .. 64 lanes: two such pairs in turn) fits the chip
     bool lstm_batchs_ok = false; // lstm_batchs_kernel (two groups of 16 lanes side by side, 16 workgroups per chain) fits the chip

@@ -170,6 +170,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         env_gemm_pp = atoi(e);
     if (const char *e = getenv("UMX_LSTM8_POLL_DELAY")) // tuning: x64 cycles between a wave's publication and its first poll (lstm_batch8.h)
         lstm8_poll_delay = atoi(e);
+    if (const char *e = getenv("UMX_LSTM8_PAIRED"))
+        env_lstm8_paired = atoi(e) != 0;
     if (const char *e = getenv("UMX_LSTM8_MIN_LANES")) // contexts of this many lanes or more (up to 32) run lstm_batch8_kernel; 99: never
         env_lstm8_min = atoi(e);
     if (const char *e = getenv("UMX_LSTM_POLL_DELAY")) // tuning: x64 cycles a dot wave of the one-track recurrence sleeps before its first poll
@@ -838,11 +840,14 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                 lstm_batch8_ok = true;
                 for (int precise = 0; precise < 2; ++precise)
                 {
-                    const void *fn = lstm_batch8_fn(Hl, precise != 0);
-                    UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm8_lds_bytes(Hl)));
-                    int v = 0;
-                    UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstm8_lds_bytes(Hl)));
-                    lstm_batch8_ok = lstm_batch8_ok && v >= 1 && 8 * 32 <= v * cus;
+                    for (int no = 1; no <= 2; ++no)
+                    {
+                        const void *fn = lstm_batch8_fn(Hl, precise != 0, no);
+                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm8_lds_bytes(Hl, no)));
+                        int v = 0;
+                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstm8_lds_bytes(Hl, no)));
+                        lstm_batch8_ok = lstm_batch8_ok && v >= 1 && 8 * 32 <= v * cus;
+                    }
                 }
             }
             lstm_batch_capacity = per_cu * cus;

@@ -170,12 +170,13 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     // 33 .. 64 lanes: two such side-by-side pairs IN TURN through the same 256 workgroups (lstm_batcht_kernel, round 5); else lstm_batch2.h
     const bool turned = !octets && groups >= 3 && groups <= 4 && lstm_batcht_ok && env_lstm_grouped;
     a.bulk = (grouped || turned) ? kBatchsBulk : groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
-    const size_t lds = octets    ? lstm8_lds_bytes(Hl)
+    const int octs = octets && env_lstm8_paired && top > LSTM8_OCTETS * LSTM8_TRACKS ? 2 : 1; // octets per workgroup, in turn
+    const size_t lds = octets    ? lstm8_lds_bytes(Hl, octs)
                        : turned  ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) + LSTMB_HSW_BYTES // (the second turn's k-range sums of h')
                        : grouped ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan)
                        : groups > 1        ? lstmb2_lds_bytes(groups, a.bulk)
                                            : lstmb_lds_bytes(a.nbp, a.bulk);
-    const void *fn = octets       ? lstm_batch8_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
+    const void *fn = octets       ? lstm_batch8_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT, octs)
                      : turned     ? lstm_batcht_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
                      : grouped    ? lstm_batchs_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
                      : groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
@@ -192,8 +193,9 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     sl.lstm_wrote_planes[layer] = writes_planes;
     sl.lstm_rows_f32[layer] = !writes_planes || a.write_f32;
     void *kargs[] = {&a};
-    // lstm_batch8.h serves 32 lanes per launch: a context of 33 .. 64 lanes runs its two halves one after the other
-    const int halves = octets && top > LSTM8_OCTETS * LSTM8_TRACKS ? 2 : 1;
+    // lstm_batch8.h with one octet per workgroup serves 32 lanes per launch: 33 .. 64 lanes as two halves one after the other
+    // (UMX_LSTM8_PAIRED=0; the default is one launch of two octets per workgroup in turn)
+    const int halves = octets && octs == 1 && top > LSTM8_OCTETS * LSTM8_TRACKS ? 2 : 1;
     auto half_on = [&](int hf) { return halves == 1 || ((lane_mask >> (32 * hf)) & 0xffffffffull) != 0; };
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
     for (int hf = 0; persistent && hf < halves; ++hf)

@@ -32,31 +32,46 @@ constexpr int LSTM8_TRACKS = 8;  // track lanes per workgroup
 constexpr int LSTM8_UNITS = 64;  // hidden units per workgroup (8 per wave)
 constexpr int LSTM8_OCTETS = 4;  // octets of a launch: 32 lanes
 #define LSTM8_RETRY_SLEEP 1 // x64 cycles between failed polls
+#define LSTM8_OOR 0x7ffffff0 // a buffer offset beyond every resource of this kernel: the store is dropped
 
 // bytes of one octet's granule area: [2 step slots][8 chains][Hl / 2 unit pairs][8 tracks] x 16 B
 __host__ __device__ inline size_t lstm8_granule_bytes(int Hl) { return (size_t)2 * 8 * (Hl / 2) * LSTM8_TRACKS * 16; }
 // LDS: h in fragment order [2 steps][Hl / 32 k-steps][4 k-groups][16 n] x 16 B, the eight k-range sums of h' [2][8 tracks][8 waves]
 __host__ __device__ inline size_t lstm8_h_bytes(int Hl) { return (size_t)(Hl / 32) * 4 * 16 * 16; }
-__host__ __device__ inline size_t lstm8_lds_bytes(int Hl) { return 2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float); }
+__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float)); } // no: octets per workgroup
 
-template <int HL, bool FAST, bool PRECISE>
-__device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int shard, int octet, unsigned char *smem, int *abort_flag)
+// NO = octets a workgroup serves IN TURN (2: launches of 33 .. 64 lanes -- octet o and octet o + 4 with the same weight fragments).
+// A step of one octet is a dependent chain  publication -> L2 -> polls (a round of loads ~1,100 cycles + ~700 until the last wave's
+// have come through the CU's one path) -> matrix phase -> gate phase, of which only the last two keep the workgroup's pipes busy
+// (profiles/r05_lstm_batch8_first.txt).  With two octets the polls of the NEXT turn are issued behind the barrier of the current one
+// -- its granules were published a whole turn ago -- and checked when that turn begins: the hand-off of one octet runs under the
+// matrix and gate phases of the other.  Per (unit, lane) the arithmetic does not know about turns: the bits of NO = 1.
+#ifndef LSTM8_EARLY_KS
+#define LSTM8_EARLY_KS 13 // the next turn's polls are issued behind this k-step of the matrix phase (-1: in front of it)
+#endif
+#ifndef LSTM8_EXPERIMENT
+#define LSTM8_EXPERIMENT 0 // timing builds only (wrong results): 1 = no request for the next row of W_ih x, 2 = no output stores inside the loop
+#endif
+#ifndef LSTM8_FRAG_AHEAD
+#define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions
+#endif
+template <int HL, bool FAST, bool PRECISE, int NO>
+__device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int shard, int octet0, unsigned char *smem, int *abort_flag)
 {
     constexpr int NKS = HL / 32;        // k-steps of the contraction
     constexpr int KSW = NKS / 8;        // k-steps whose sum of h' wave w forms
     constexpr int NLD = HL * 4 / 512;   // granules a thread polls per step
     constexpr int GPS = HL * 4;         // granules per (slot, chain): HL / 2 pairs x 8 tracks
-    static_assert(HL % 256 == 0, "eight waves x 32-unit k-steps");
+    constexpr int HB = (HL / 32) * 4 * 16 * 16;         // = lstm8_h_bytes(HL)
+    static_assert(HL % 256 == 0 && (NO == 1 || NO == 2), "eight waves x 32-unit k-steps; one octet or two in turn");
     const int target = a.tmap[chain >> 1], dir = chain & 1, wchain = target * 2 + dir;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, q = l >> 4;
     const int tr = n & 7, tile = n >> 3; // the cell this lane finishes: track tr of the octet, unit 4 tile + q of the wave's eight
-    const int lane0 = a.lane_base + LSTM8_TRACKS * octet, T = a.T, S = a.S;
-    const unsigned mask8 = (unsigned)(a.lane_mask >> lane0) & 0xffu;
-    const bool lane_on = (mask8 >> tr) & 1u;
+    const int T = a.T, S = a.S;
     const int U = shard * LSTM8_UNITS + w * 8 + tile * 4 + q; // hidden unit of the chain
 
-    unsigned char *const hl = smem;                                                      // [2][NKS][4][16] x 16 B
-    float *const hsp = reinterpret_cast<float *>(smem + 2 * lstm8_h_bytes(HL));          // [2][8 tracks][8 waves]
+    unsigned char *const hl = smem;                                                        // [NO][2][NKS][4][16] x 16 B
+    float *const hsp = reinterpret_cast<float *>(smem + (size_t)NO * 2 * HB);              // [NO][2][8 tracks][8 waves]
 
     // ---- W_hh fragments of the wave's two M tiles: lane (i = l & 15, q) holds gate column 16 mt + i (unit 4 mt + i / 4, gate i % 4), k = 32 ks + 8 q + j
     f16x8 Wf[2][NKS];
@@ -80,38 +95,65 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                     hw[j] = (_Float16)((float)wp[mt][(size_t)(32 * ks + j) * 64] - 128.0f); // an integer in [-128, 127]: exact
                 Wf[mt][ks] = hw;
             }
-            asm volatile("" ::: "memory"); // (sixteen byte loads in flight, not 256: the prologue does not spill)
+            asm volatile("" ::: "memory"); // (sixteen byte loads in flight, not 256)
         }
     }
     constexpr float HSCALE = 16384.0f;
     const float wsc = a.wsc[wchain] * (1.0f / HSCALE), wof2 = (a.wof[wchain] + 128.0f * a.wsc[wchain]) * (1.0f / HSCALE);
-
-    // ---- this lane's cell
-    const size_t st_h = (size_t)(lane0 + tr) * a.state_stride + state_off(target, a.layer, dir, 0, HL);
-    const size_t st_c = (size_t)(lane0 + tr) * a.state_stride + state_off(target, a.layer, dir, 1, HL);
     const float4 bh = *reinterpret_cast<const float4 *>(a.bhh + ((size_t)wchain * S + (U >> 4)) * 64 + 4 * (U & 15));
-    float c = 0.f, hlast = 0.f;
-    if (lane_on)
-    {
-        c = a.state[st_c + U];
-        hlast = a.state[st_h + U];
-    }
-    unsigned plast = 0; // the fp16 planes of hlast (h1 | h2 << 16)
 
     // ---- what this thread polls: granule g = i 512 + tid of its (chain, octet): k-step g / 128, k-group (g / 32) % 4, pair (g / 8) % 4, track g % 8
     const int p_tr = tid & 7, p_pair = (tid >> 3) & 3, p_q = (tid >> 5) & 3, p_ks0 = tid >> 7;
-    const bool p_on = (mask8 >> p_tr) & 1u;
     const int lds_w = ((p_ks0 * 4 + p_q) * 16 + p_tr) * 16 + p_pair * 4; // + i (4 x 1024) for load i; + 128 for the second plane
     const int t_begin = a.t_begin, t_end = a.t_end, poll_delay = a.poll_delay;
-    // h_{t_begin - 1} from the fp32 stream state, split like a published granule; absent tracks are zero columns in both buffers
+    const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo, plane_elems = a.plane_elems, ldpl = (size_t)a.ldpl;
+    const unsigned tag_hi = a.tag_epoch << 12;
+    const int gbase = chain * GPS * 16, gslot = 8 * GPS * 16; // bytes
+    const int pub_off = gbase + (((U >> 3) * 4 + ((U & 7) >> 1)) * 8 + tr) * 16;
+    gu32 *status = (gu32 *)a.status;
+
+    // ---- per octet: this lane's cell, its rows, the granule area
+    bool on[NO], lane_on[NO], p_on[NO];
+    float c[NO], hlast[NO];
+    unsigned plast[NO]; // the fp16 planes of hlast (h1 | h2 << 16)
+    float4 p4n[NO];
+    const float *Pg[NO];
+    float *outp[NO];
+    int rs_off[NO]; // byte offset of this lane's row sums (LSTM8_OOR: none)
+    unsigned short *plp[NO];
+    __amdgpu_buffer_rsrc_t gran_rs[NO];
+    int lane0[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
     {
-        const size_t sh = (size_t)(lane0 + p_tr) * a.state_stride + state_off(target, a.layer, dir, 0, HL);
+        const int octet = octet0 + o * LSTM8_OCTETS;
+        lane0[o] = a.lane_base + LSTM8_TRACKS * octet;
+        const unsigned mask8 = (unsigned)(a.lane_mask >> lane0[o]) & 0xffu;
+        on[o] = mask8 != 0u;
+        lane_on[o] = (mask8 >> tr) & 1u;
+        p_on[o] = (mask8 >> p_tr) & 1u;
+        const size_t st = (size_t)(lane0[o] + tr) * a.state_stride;
+        c[o] = lane_on[o] ? a.state[st + state_off(target, a.layer, dir, 1, HL) + U] : 0.f;
+        hlast[o] = lane_on[o] ? a.state[st + state_off(target, a.layer, dir, 0, HL) + U] : 0.f;
+        plast[o] = 0u;
+        Pg[o] = a.P[target] + (size_t)(lane0[o] + tr) * a.p_stride + ((size_t)dir * S + (U >> 4)) * 64 + 4 * (U & 15);
+        outp[o] = a.out[target] + (size_t)(lane0[o] + tr) * a.out_stride + a.col0 + dir * HL + U;
+        plp[o] = a.planes[target] ? a.planes[target] + (size_t)(lane0[o] + tr) * a.Tp * a.ldpl + a.col0 + dir * HL + U : nullptr;
+        // the row sum the consuming GEMM's affine fix-up needs = Hs of the step that multiplies with the row: one lane per track of the chain's first wave
+        rs_off[o] = (shard == 0 && w == 0 && l < 8 && lane_on[o]) ? (int)(((size_t)dir * a.rs_rows + (size_t)(lane0[o] + tr) * a.Tp) * 4) : LSTM8_OOR;
+        gran_rs[o] = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char *>(a.sync + LSTM_SYNC_HEADER_WORDS) + (size_t)octet * lstm8_granule_bytes(HL), 0,
+                                                       (int)lstm8_granule_bytes(HL), 0x00020000);
+        p4n[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane_on[o] && t_begin < t_end)
+            p4n[o] = *reinterpret_cast<const float4 *>(Pg[o] + (size_t)(dir == 0 ? t_begin : T - 1 - t_begin) * ldp);
+        // h_{t_begin - 1} from the fp32 stream state, split like a published granule; absent tracks are zero columns in both buffers
+        const size_t sh = (size_t)(lane0[o] + p_tr) * a.state_stride + state_off(target, a.layer, dir, 0, HL);
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
         {
             const int k0 = (i * 4 + p_ks0) * 32 + p_q * 8 + p_pair * 2;
             unsigned d1 = 0u, d2 = 0u;
-            if (p_on)
+            if (p_on[o])
             {
                 const float x0 = a.state[sh + k0] * HSCALE, x1 = a.state[sh + k0 + 1] * HSCALE;
                 const _Float16 a1 = (_Float16)x0, b1 = (_Float16)x1;
@@ -119,238 +161,280 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 d1 = (unsigned)__builtin_bit_cast(unsigned short, a1) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
                 d2 = (unsigned)__builtin_bit_cast(unsigned short, a2) | ((unsigned)__builtin_bit_cast(unsigned short, b2) << 16);
             }
-            unsigned char *dst = hl + (size_t)(t_begin & 1) * lstm8_h_bytes(HL) + lds_w + i * 4096;
+            unsigned char *dst = hl + (size_t)(o * 2 + (t_begin & 1)) * HB + lds_w + i * 4096;
             *reinterpret_cast<unsigned *>(dst) = d1;
             *reinterpret_cast<unsigned *>(dst + 128) = d2;
-            if (!p_on)
+            if (!p_on[o])
             {
-                unsigned char *other = hl + (size_t)((t_begin & 1) ^ 1) * lstm8_h_bytes(HL) + lds_w + i * 4096;
+                unsigned char *other = hl + (size_t)(o * 2 + ((t_begin & 1) ^ 1)) * HB + lds_w + i * 4096;
                 *reinterpret_cast<unsigned *>(other) = 0u;
                 *reinterpret_cast<unsigned *>(other + 128) = 0u;
             }
         }
     }
-
-    const __amdgpu_buffer_rsrc_t gran_rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<unsigned char *>(a.sync + LSTM_SYNC_HEADER_WORDS) + (size_t)octet * lstm8_granule_bytes(HL), 0, (int)lstm8_granule_bytes(HL), 0x00020000);
-    gu32 *status = (gu32 *)a.status;
-    const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo;
-    const float *const Pg = a.P[target] + (size_t)(lane0 + tr) * a.p_stride + ((size_t)dir * S + (U >> 4)) * 64 + 4 * (U & 15);
-    float *const outp = a.out[target] + (size_t)(lane0 + tr) * a.out_stride + a.col0 + dir * HL + U;
-    unsigned short *const plp = a.planes[target] ? a.planes[target] + (size_t)(lane0 + tr) * a.Tp * a.ldpl + a.col0 + dir * HL + U : nullptr;
-    const size_t plane_elems = a.plane_elems, ldpl = (size_t)a.ldpl;
-    // the row sum the consuming GEMM's affine fix-up needs = Hs of the step that multiplies with the row: one lane per track of the chain's first wave
-    float *const rsp = (a.rs_dir[target] && shard == 0 && w == 0 && l < 8 && lane_on) ? a.rs_dir[target] + (size_t)dir * a.rs_rows + (size_t)(lane0 + tr) * a.Tp : nullptr;
-    const unsigned tag_hi = a.tag_epoch << 12;
-    const int gbase = chain * GPS * 16, gslot = 8 * GPS * 16; // bytes
-    const int pub_off = gbase + (((U >> 3) * 4 + ((U & 7) >> 1)) * 8 + tr) * 16;
-    float4 p4n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane_on && t_begin < t_end)
-        p4n = *reinterpret_cast<const float4 *>(Pg + (size_t)(dir == 0 ? t_begin : T - 1 - t_begin) * ldp);
+    // Publication and row sums go out as buffer stores that EVERY lane issues (lanes with nothing to store: an offset beyond the
+    // resource, dropped by the range check): no branch around them, so the compiler knows how many memory operations follow the polls
+    // issued during a turn, and the wait in front of their check does not include these stores' acknowledgements.
+    const __amdgpu_buffer_rsrc_t rs_rs =
+        __builtin_amdgcn_make_buffer_rsrc(a.rs_dir[target], 0, a.rs_dir[target] ? (int)((size_t)2 * a.rs_rows * 4) : 0, 0x00020000);
+    const bool both_on = NO == 2 && on[0] && on[NO - 1]; // the turns overlap each other's hand-off only if there are two
     __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): weights, bias, state have arrived (no "wait for everything" inside the loop)
-    const bool prof = a.prof != nullptr && octet == 0 && chain == 0 && shard == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
+    const bool prof = a.prof != nullptr && octet0 == 0 && chain == 0 && shard == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
     const int pw_idx = w == 0 ? 0 : 1;
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pc6 = 0, pc7 = 0;
     unsigned prof_spins = 0;
     const f16x8 ones16 = __builtin_bit_cast(f16x8, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));
 #define LSTM8_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") // LDS only: __syncthreads() is also a vmcnt(0) fence
+    typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+    v3u32 v[NLD];         // the polls of one turn: {tag, h1 pair, h2 pair} = the first 12 bytes of a granule (its fourth dword is unused: a
+                          // register nobody reads would be handed out again while the load is still in flight -- and waited for)
+    bool pending = false; // ... issued during the turn before
+    const int goff0 = gbase + tid * 16;
+#define LSTM8_POLL(o_, step_)                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) v[i] =                                                                                \
+        __builtin_amdgcn_raw_buffer_load_b96(gran_rs[o_], (((step_)-1) & 1) * gslot + goff0 + i * 512 * 16, 0, 16) /* sc1 */
 
     for (int step = t_begin; step < t_end; ++step)
     {
-        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        if (prof)
-            c0 = clock64();
-        unsigned char *const hb = hl + (size_t)(step & 1) * lstm8_h_bytes(HL);
         if (a.abort_at && step == a.abort_at && tid == 0)
         {
             __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *abort_flag = 1;
         }
-        if (step > t_begin)
-        {
-            // h_{step-1}: the granules of slot (step-1)&1 tagged `step`
-            const unsigned want = tag_hi | (unsigned)step;
-            const int goff = ((step - 1) & 1) * gslot + gbase + tid * 16;
-            if (FAST)
-                for (int d = poll_delay; d > 0; --d)
-                    __builtin_amdgcn_s_sleep(1);
-            uint4 v[NLD];
-            unsigned spins = 0;
-            for (;;)
-            {
-                bool ok = true;
-                if (p_on)
-                {
 #pragma unroll
-                    for (int i = 0; i < NLD; ++i)
-                        v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gran_rs, goff + i * 512 * 16, 0, 16)); // sc1
+        for (int o = 0; o < NO; ++o)
+        {
+            if (NO > 1 && !on[o])
+                continue;
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, ca = 0;
+            if (prof)
+                ca = c0 = clock64();
+            unsigned char *const hb = hl + (size_t)(o * 2 + (step & 1)) * HB;
+            float *const hs = hsp + (o * 2 + (step & 1)) * 64;
+            if (step > t_begin)
+            {
+                // h_{step-1}: the granules of slot (step-1)&1 tagged `step`
+                const unsigned want = tag_hi | (unsigned)step;
+                if (FAST && !pending)
+                    for (int d = poll_delay; d > 0; --d)
+                        __builtin_amdgcn_s_sleep(1);
+                unsigned spins = 0;
+                auto tags_bad = [&]() {
                     unsigned bad = 0;
 #pragma unroll
                     for (int i = 0; i < NLD; ++i)
                         bad |= v[i].x ^ want;
-                    ok = bad == 0;
-                }
-                if (__all(ok))
-                    break;
-                if (++spins > LSTM_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                    return bad;
+                };
+                // two code paths on purpose: the wait in front of a check covers everything issued before it on ANY path into it, and
+                // behind polls issued a turn ago sit that turn's publication and row-sum stores -- whose acknowledgements are not needed here
+                bool ok = true;
+                if (pending)
                 {
-                    if (l == 0)
-                        __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    *abort_flag = 1;
-                    break;
+                    if (p_on[o])
+                        ok = tags_bad() == 0u;
                 }
-                __builtin_amdgcn_s_sleep(LSTM8_RETRY_SLEEP);
-            }
-            prof_spins = spins;
-            if (p_on)
-            {
-#pragma unroll
-                for (int i = 0; i < NLD; ++i)
+                else if (p_on[o])
                 {
-                    *reinterpret_cast<unsigned *>(hb + lds_w + i * 4096) = v[i].y;       // h1 of the pair
-                    *reinterpret_cast<unsigned *>(hb + lds_w + i * 4096 + 128) = v[i].z; // h2 of the pair
+                    LSTM8_POLL(o, step);
+                    ok = tags_bad() == 0u;
+                }
+                pending = false;
+                while (!__all(ok))
+                {
+                    if (++spins > LSTM_SPIN_LIMIT || ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                    {
+                        if (l == 0)
+                            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *abort_flag = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(LSTM8_RETRY_SLEEP);
+                    if (p_on[o])
+                    {
+                        LSTM8_POLL(o, step);
+                        ok = tags_bad() == 0u;
+                    }
+                }
+                prof_spins = spins;
+                if (prof)
+                    ca = clock64(); // (the check is through: the polls are there)
+                if (p_on[o])
+                {
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i)
+                    {
+                        *reinterpret_cast<unsigned *>(hb + lds_w + i * 4096) = v[i].y;       // h1 of the pair
+                        *reinterpret_cast<unsigned *>(hb + lds_w + i * 4096 + 128) = v[i].z; // h2 of the pair
+                    }
                 }
             }
-        }
-        // the output row of the PREVIOUS step goes out behind the polls (vector memory operations complete in order)
-        if (lane_on && step > t_begin)
-        {
-            const size_t fr = (size_t)(dir == 0 ? step - 1 : T - step);
-            if (!plp || a.write_f32)
-                outp[fr * ldo] = hlast; // lstm.cpp:163-164,170-171
-            if (plp)
+            // the output row of the PREVIOUS step and the request for the next row of W_ih x go out behind the polls (vector memory
+            // operations complete in order).  (Behind the barrier instead, under the matrix phase: the ~300 cycles their issue takes on
+            // the CU's one address path then stall the wave's matrix instructions for longer -- 5.85 against 5.5 ms per 32-lane launch.)
+            // (The row's two planes as ONE dword store per lane -- the even unit of a pair writing (h1, h1') into plane 0, the odd unit
+            // (h2, h2') into plane 1 -- saves a store instruction and costs more in the gate phase: 9.7 against 9.4 ms per 64-lane launch.)
+            if (!(LSTM8_EXPERIMENT & 2) && lane_on[o] && step > t_begin)
             {
-                plp[fr * ldpl] = (unsigned short)(plast & 0xffffu);
-                plp[plane_elems + fr * ldpl] = (unsigned short)(plast >> 16);
+                const size_t fr = (size_t)(dir == 0 ? step - 1 : T - step);
+                if (!plp[o] || a.write_f32)
+                    outp[o][fr * ldo] = hlast[o]; // lstm.cpp:163-164,170-171
+                if (plp[o])
+                {
+                    plp[o][fr * ldpl] = (unsigned short)(plast[o] & 0xffffu);
+                    plp[o][plane_elems + fr * ldpl] = (unsigned short)(plast[o] >> 16);
+                }
             }
-        }
-        const float4 p4 = p4n; // row `step` of W_ih x + b_ih, requested a step ago
-        if (lane_on && step + 1 < t_end)
-            p4n = *reinterpret_cast<const float4 *>(Pg + (size_t)(dir == 0 ? step + 1 : T - 2 - step) * ldp);
-        if (prof)
-            c1 = clock64();
-        LSTM8_LDS_BARRIER(); // h_{step-1} is in LDS
-        if (*abort_flag)
-            return;
-        if (prof)
-            c2 = clock64();
+            const float4 p4 = p4n[o]; // row `step` of W_ih x + b_ih, requested a step ago
+            if (!(LSTM8_EXPERIMENT & 1) && lane_on[o] && step + 1 < t_end)
+                p4n[o] = *reinterpret_cast<const float4 *>(Pg[o] + (size_t)(dir == 0 ? step + 1 : T - 2 - step) * ldp);
+            if (prof)
+                c1 = clock64();
+            LSTM8_LDS_BARRIER(); // h_{step-1} is in LDS
+            if (*abort_flag)
+                return;
+            if (prof)
+                c2 = clock64();
+            // the next turn's polls: the other octet's granules were published a turn ago
+            const int no = NO - 1 - o, nstep = o + 1 < NO ? step : step + 1;
+            const bool issue_next = NO > 1 && both_on && nstep > t_begin && nstep < t_end;
 
-        // ---- matrix phase: the sum of h' over this wave's k-steps first (its LDS round trip hides behind the products)
-        const unsigned char *const fb = hb + (q * 16 + n) * 16;
-        floatx4 accH = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            // ---- matrix phase: ONE basic block (the k-range sum of h' is stored by every lane -- all 64 hold the sum of their column's
+            // track -- and the next turn's polls are loads every lane issues, out of range where there is nothing to poll), fragments
+            // read LSTM8_FRAG_AHEAD k-steps ahead of the products that take them
+            const unsigned char *const fb = hb + (q * 16 + n) * 16;
+            floatx4 accH = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f16x8 bf[LSTM8_FRAG_AHEAD];
 #pragma unroll
-        for (int kk = 0; kk < KSW; ++kk)
-            accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones16, *reinterpret_cast<const f16x8 *>(fb + (w * KSW + kk) * 1024), accH, 0, 0, 0);
+            for (int i = 0; i < LSTM8_FRAG_AHEAD; ++i)
+                bf[i] = *reinterpret_cast<const f16x8 *>(fb + i * 1024);
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks)
-        {
-            const f16x8 bf = *reinterpret_cast<const f16x8 *>(fb + ks * 1024);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][ks], bf, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][ks], bf, acc1, 0, 0, 0);
-            if (ks == 3)
+            for (int kk = 0; kk < KSW; ++kk)
+                accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones16, *reinterpret_cast<const f16x8 *>(fb + (w * KSW + kk) * 1024), accH, 0, 0, 0);
+            const int poll_base = (NO > 1 && issue_next && p_on[no]) ? ((nstep - 1) & 1) * gslot + goff0 : LSTM8_OOR;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
             {
-                // (every row of accH holds the same sums; column n: plane n / 8 of track n % 8)
-                const float hp = accH[0] + __int_as_float(dpp_row_ror<8>(__float_as_int(accH[0])));
-                if (l < 8)
-                    hsp[((step & 1) * 8 + l) * 8 + w] = hp;
+                const f16x8 cur = bf[ks % LSTM8_FRAG_AHEAD];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[0][ks], cur, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][ks], cur, acc1, 0, 0, 0);
+                if (ks + LSTM8_FRAG_AHEAD < NKS)
+                    bf[ks % LSTM8_FRAG_AHEAD] = *reinterpret_cast<const f16x8 *>(fb + (ks + LSTM8_FRAG_AHEAD) * 1024);
+                if (ks == 3) // (every row of accH holds the same sums; column n: plane n / 8 of track n % 8)
+                    hs[tr * 8 + w] = accH[0] + __int_as_float(dpp_row_ror<8>(__float_as_int(accH[0])));
+                if (NO > 1 && ks == (LSTM8_EARLY_KS < 0 ? 0 : LSTM8_EARLY_KS))
+                {
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i)
+                        v[i] = __builtin_amdgcn_raw_buffer_load_b96(gran_rs[no], poll_base == LSTM8_OOR ? LSTM8_OOR : poll_base + i * 512 * 16, 0, 16); // sc1
+                    pending = issue_next;
+                }
             }
-        }
-        LSTM8_LDS_BARRIER(); // the eight k-range sums of h' are in LDS
-        if (prof)
-            c3 = clock64();
+            LSTM8_LDS_BARRIER(); // the eight k-range sums of h' are in LDS
+            if (prof)
+                c3 = clock64();
 
-        // ---- gate phase: one cell per lane
-        {
-            const float4 ha = *reinterpret_cast<const float4 *>(hsp + ((step & 1) * 8 + tr) * 8), hc = *reinterpret_cast<const float4 *>(hsp + ((step & 1) * 8 + tr) * 8 + 4);
-            const float hp8[8] = {ha.x, ha.y, ha.z, ha.w, hc.x, hc.y, hc.z, hc.w};
-            const float Hs = tree_sum<8>(hp8);
-            if (rsp && step > 0) // the row that this step multiplied with (step 0 multiplies with the carried state, not a row)
-                rsp[(size_t)(dir == 0 ? step - 1 : T - step)] = Hs * (1.0f / 16384.0f);
-            const float hterm = wof2 * Hs;
-            float s[4];
+            // ---- gate phase: one cell per lane
+            {
+                const float4 ha = *reinterpret_cast<const float4 *>(hs + tr * 8), hc = *reinterpret_cast<const float4 *>(hs + tr * 8 + 4);
+                const float hp8[8] = {ha.x, ha.y, ha.z, ha.w, hc.x, hc.y, hc.z, hc.w};
+                const float Hs = tree_sum<8>(hp8);
+                // the row that this step multiplied with (step 0 multiplies with the carried state, not a row)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Hs * (1.0f / 16384.0f)), rs_rs,
+                                                      (rs_off[o] != LSTM8_OOR && step > 0) ? rs_off[o] + (dir == 0 ? step - 1 : T - step) * 4 : LSTM8_OOR, 0, 0);
+                const float hterm = wof2 * Hs;
+                float s[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                // lanes n < 8 finish tile 0: own column (plane 0) + column n + 8 (plane 1); lanes n >= 8 tile 1: own (plane 1) + column n - 8
-                const float mine = tile ? acc1[r] : acc0[r], theirs = tile ? acc0[r] : acc1[r];
-                const float sum = mine + __int_as_float(dpp_row_ror<8>(__float_as_int(theirs)));
-                s[r] = wsc * sum + hterm;
+                for (int r = 0; r < 4; ++r)
+                {
+                    // lanes n < 8 finish tile 0: own column (plane 0) + column n + 8 (plane 1); lanes n >= 8 tile 1: own (plane 1) + column n - 8
+                    const float mine = tile ? acc1[r] : acc0[r], theirs = tile ? acc0[r] : acc1[r];
+                    const float sum = mine + __int_as_float(dpp_row_ror<8>(__float_as_int(theirs)));
+                    s[r] = wsc * sum + hterm;
+                }
+                // ((W_ih x + b_ih) + W_hh h) + b_hh, lstm.cpp:132-140
+                const float pre_i = (p4.x + s[0]) + bh.x, pre_f = (p4.y + s[1]) + bh.y, pre_g = (p4.z + s[2]) + bh.z, pre_o = (p4.w + s[3]) + bh.w;
+                float i_t, f_t, g_t, o_t;
+                if (PRECISE)
+                {
+                    i_t = sigmoid_ref(pre_i);
+                    f_t = sigmoid_ref(pre_f);
+                    g_t = tanhf(pre_g);
+                    o_t = sigmoid_ref(pre_o);
+                }
+                else
+                {
+                    i_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_i));
+                    f_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_f));
+                    g_t = tanh_hw(pre_g);
+                    o_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_o));
+                }
+                const float c_t = f_t * c[o] + i_t * g_t;                     // lstm.cpp:154-156
+                const float h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
+                const float hs14 = h * HSCALE;
+                const _Float16 h1 = (_Float16)hs14, h2 = (_Float16)(hs14 - (float)h1);
+                const unsigned b1 = __builtin_bit_cast(unsigned short, h1), b2 = __builtin_bit_cast(unsigned short, h2);
+                const unsigned mine12 = b1 | (b2 << 16);
+                // the odd unit of the pair sits 16 lanes up: row r + 1 into row r
+                const unsigned other12 = __builtin_amdgcn_permlane16_swap(mine12, mine12, false, false)[1];
+                if (lane_on[o])
+                {
+                    c[o] = c_t;
+                    hlast[o] = h;
+                    plast[o] = mine12;
+                }
+                // the even unit of a pair publishes it (this unit, the next), tagged step + 1
+                granule_store16<FAST>(gran_rs[o], (lane_on[o] && (q & 1) == 0) ? (step & 1) * gslot + pub_off : LSTM8_OOR,
+                                      make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u), 0u));
             }
-            // ((W_ih x + b_ih) + W_hh h) + b_hh, lstm.cpp:132-140
-            const float pre_i = (p4.x + s[0]) + bh.x, pre_f = (p4.y + s[1]) + bh.y, pre_g = (p4.z + s[2]) + bh.z, pre_o = (p4.w + s[3]) + bh.w;
-            float i_t, f_t, g_t, o_t;
-            if (PRECISE)
+            if (prof)
             {
-                i_t = sigmoid_ref(pre_i);
-                f_t = sigmoid_ref(pre_f);
-                g_t = tanhf(pre_g);
-                o_t = sigmoid_ref(pre_o);
+                const long long c4 = clock64();
+                pc[0] += (unsigned long long)(c1 - c0);
+                pc[1] += (unsigned long long)(c3 - c2);
+                pc[2] += (unsigned long long)(c2 - c1);
+                pc[3] += (unsigned long long)(c4 - c3);
+                pc[4] += 1;
+                pc[5] += prof_spins;
+                pc6 += (unsigned long long)(ca - c0);
+                pc7 += (unsigned long long)(c1 - ca);
             }
-            else
-            {
-                i_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_i));
-                f_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_f));
-                g_t = tanh_hw(pre_g);
-                o_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_o));
-            }
-            const float c_t = f_t * c + i_t * g_t;                        // lstm.cpp:154-156
-            const float h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
-            const float hs14 = h * HSCALE;
-            const _Float16 h1 = (_Float16)hs14, h2 = (_Float16)(hs14 - (float)h1);
-            const unsigned b1 = __builtin_bit_cast(unsigned short, h1), b2 = __builtin_bit_cast(unsigned short, h2);
-            const unsigned mine12 = b1 | (b2 << 16);
-            // the odd unit of the pair sits 16 lanes up: row r + 1 into row r
-            const unsigned other12 = __builtin_amdgcn_permlane16_swap(mine12, mine12, false, false)[1];
-            if (lane_on)
-            {
-                c = c_t;
-                hlast = h;
-                plast = mine12;
-                if ((q & 1) == 0) // publish the pair (this unit, the next), tagged step + 1
-                    granule_store16<FAST>(gran_rs, (step & 1) * gslot + pub_off,
-                                          make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u), 0u));
-            }
-        }
-        if (prof)
-        {
-            const long long c4 = clock64();
-            pc[0] += (unsigned long long)(c1 - c0);
-            pc[1] += (unsigned long long)(c3 - c2);
-            pc[2] += (unsigned long long)(c2 - c1);
-            pc[3] += (unsigned long long)(c4 - c3);
-            pc[4] += 1;
-            pc[5] += prof_spins;
         }
     }
 #undef LSTM8_LDS_BARRIER
-    if (lane_on) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
-    {
-        if (t_end > t_begin)
+#undef LSTM8_POLL
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+        if (lane_on[o]) // lstm.cpp:160-161: the state carries into the next segment (and the next launch)
         {
-            const size_t fr = (size_t)(dir == 0 ? t_end - 1 : T - t_end);
-            outp[fr * ldo] = hlast;
-            if (plp)
+            if (t_end > t_begin)
             {
-                plp[fr * ldpl] = (unsigned short)(plast & 0xffffu);
-                plp[plane_elems + fr * ldpl] = (unsigned short)(plast >> 16);
+                const size_t fr = (size_t)(dir == 0 ? t_end - 1 : T - t_end);
+                outp[o][fr * ldo] = hlast[o];
+                if (plp[o])
+                {
+                    plp[o][fr * ldpl] = (unsigned short)(plast[o] & 0xffffu);
+                    plp[o][plane_elems + fr * ldpl] = (unsigned short)(plast[o] >> 16);
+                }
             }
+            const size_t st = (size_t)(lane0[o] + tr) * a.state_stride;
+            a.state_out[st + state_off(target, a.layer, dir, 0, HL) + U] = hlast[o];
+            a.state_out[st + state_off(target, a.layer, dir, 1, HL) + U] = c[o];
         }
-        a.state_out[st_h + U] = hlast;
-        a.state_out[st_c + U] = c;
-    }
     if (prof && l == 0)
     {
         for (int i = 0; i < 6; ++i)
             a.prof[(a.layer * 2 + pw_idx) * 8 + i] = (t_begin == 0 ? 0ull : a.prof[(a.layer * 2 + pw_idx) * 8 + i]) + pc[i];
-        a.prof[(a.layer * 2 + pw_idx) * 8 + 6] = 0;
-        a.prof[(a.layer * 2 + pw_idx) * 8 + 7] = 0;
+        a.prof[(a.layer * 2 + pw_idx) * 8 + 6] = pc6; // until the polls' check is through
+        a.prof[(a.layer * 2 + pw_idx) * 8 + 7] = pc7; // LDS writes, the previous row's stores, the next row's request
     }
 }
 
 // grid: persistent (census = 1) 8 chains x 32 workgroups -- every XCD must receive 32 (one per CU): ticket / (HL / 64) picks one of the
 // XCD's virtual chains (octet, chain), ticket % (HL / 64) the column shard, so that a hand-off domain lives on ONE XCD;
-// one step per launch (census = 0): static roles, grid = octets x chains of the launch x shards.
-template <int HL, bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS, 2) void lstm_batch8_kernel(LstmBArgs a)
+// one step per launch (census = 0): static roles, grid = octets x chains of the launch x shards.  NO = 2: the workgroup of octet o also
+// serves octet o + 4 (launches of 33 .. 64 lanes).
+template <int HL, bool PRECISE, int NO> __global__ __launch_bounds__(LSTM_THREADS, 2) void lstm_batch8_kernel(LstmBArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lstm8_smem[];
     __shared__ int s_ctl[4]; // chain, shard (or ticket), fast, abort
@@ -382,13 +466,15 @@ template <int HL, bool PRECISE> __global__ __launch_bounds__(LSTM_THREADS, 2) vo
         shard = (int)blockIdx.x % NSH;
     }
     const int octet = vc >> 3, chain = vc & 7;
-    const unsigned mask8 = (unsigned)(a.lane_mask >> (a.lane_base + LSTM8_TRACKS * octet)) & 0xffu;
-    if (chain >= a.nchains || mask8 == 0u)
+    unsigned mask = (unsigned)(a.lane_mask >> (a.lane_base + LSTM8_TRACKS * octet)) & 0xffu;
+    if (NO > 1)
+        mask |= (unsigned)(a.lane_mask >> (a.lane_base + LSTM8_TRACKS * (octet + LSTM8_OCTETS))) & 0xffu;
+    if (chain >= a.nchains || mask == 0u)
         return;
     if (s_ctl[2])
-        lstm8_body<HL, true, PRECISE>(a, chain, shard, octet, lstm8_smem, &s_ctl[3]);
+        lstm8_body<HL, true, PRECISE, NO>(a, chain, shard, octet, lstm8_smem, &s_ctl[3]);
     else
-        lstm8_body<HL, false, PRECISE>(a, chain, shard, octet, lstm8_smem, &s_ctl[3]);
+        lstm8_body<HL, false, PRECISE, NO>(a, chain, shard, octet, lstm8_smem, &s_ctl[3]);
 }
 
 } // namespace umx
