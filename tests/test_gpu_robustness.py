@@ -69,7 +69,7 @@ def test_two_umxl_contexts_from_two_threads(pkg, umxl):
         engs[k].close()
 
 
-@pytest.mark.parametrize("tracks", [1, 3, 19, 37])  # 19: two groups of lanes side by side (lstm_batchs_kernel); 37: two such pairs in turn, one group empty (lstm_batcht_kernel)
+@pytest.mark.parametrize("tracks", [1, 3, 19, 37])  # 19: three octets of lanes (lstm_batch8_kernel, one per workgroup); 37: two octets per workgroup in turn, most second octets empty
 def test_timeout_is_recovered_with_the_same_bits(pkg, umxl, tracks):
     import torch
     torch.zeros(1).cuda()

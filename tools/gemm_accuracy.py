@@ -8,8 +8,8 @@ reference would use (fl(q*scale+offset), model.cpp:610-616):
   3-layer BiLSTM           2584-step-class recurrence, u8 W_hh, from the engine's fc1 output (torch float64 LSTM)
 for the GEMM flavours planes / bf16x3 (staged split), the single-track (VALU) and the batched (matrix-core) LSTM kernels, and the
 CPU oracle (fp32).  "32 lanes (shipped)" is the configuration the bench times: the launches are large enough for the 256 x 256
-ping-pong plane GEMM (csrc/gemm_planes_pp.h) and run the recurrence as two groups side by side (lstm_batchs_kernel, csrc/lstm_batch.h);
-the one- and two-lane rows run the 128 x 128 lock-step tiles and lstm_batch_kernel (same arithmetic per element, tested bitwise).  (The fp32-MFMA flavour of rounds 1-2 is gone; its figures are in profiles/r02_accuracy_vs_float64.txt.)"""
+ping-pong plane GEMM (csrc/gemm_planes_pp.h) and run the recurrence in workgroups of 8 lanes x 64 units (lstm_batch8_kernel, csrc/lstm_batch8.h);
+the one- and two-lane rows run the 128 x 128 lock-step tiles and the same recurrence kernel (same arithmetic per element, tested bitwise).  (The fp32-MFMA flavour of rounds 1-2 is gone; its figures are in profiles/r02_accuracy_vs_float64.txt.)"""
 import sys
 import tempfile
 from pathlib import Path
