@@ -38,7 +38,7 @@ constexpr int LSTM8_OCTETS = 4;  // octets of a launch: 32 lanes
 __host__ __device__ inline size_t lstm8_granule_bytes(int Hl) { return (size_t)2 * 8 * (Hl / 2) * LSTM8_TRACKS * 16; }
 // LDS: h in fragment order [2 steps][Hl / 32 k-steps][4 k-groups][16 n] x 16 B, the eight k-range sums of h' [2][8 tracks][8 waves]
 __host__ __device__ inline size_t lstm8_h_bytes(int Hl) { return (size_t)(Hl / 32) * 4 * 16 * 16; }
-__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float)); } // no: octets per workgroup
+__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float) + 2 * 8 * LSTM8_UNITS * 2); } // no: octets per workgroup; + the row's planes staged for their store
 
 // NO = octets a workgroup serves IN TURN (2: launches of 33 .. 64 lanes -- octet o and octet o + 4 with the same weight fragments).
 // A step of one octet is a dependent chain  publication -> L2 -> polls (a round of loads ~1,100 cycles + ~700 until the last wave's
@@ -51,6 +51,9 @@ __host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (
 #endif
 #ifndef LSTM8_EXPERIMENT
 #define LSTM8_EXPERIMENT 0 // timing builds only (wrong results): 1 = no request for the next row of W_ih x, 2 = no output stores inside the loop
+#endif
+#ifndef LSTM8_STAGE_PLANES
+#define LSTM8_STAGE_PLANES 1 // the row's fused A planes go through LDS and leave as two 16-byte store instructions per turn (0: two 2-byte stores per lane)
 #endif
 #ifndef LSTM8_FRAG_AHEAD
 #define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions
@@ -72,6 +75,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
 
     unsigned char *const hl = smem;                                                        // [NO][2][NKS][4][16] x 16 B
     float *const hsp = reinterpret_cast<float *>(smem + (size_t)NO * 2 * HB);              // [NO][2][8 tracks][8 waves]
+    unsigned short *const stg = reinterpret_cast<unsigned short *>(smem + (size_t)NO * (2 * HB + 2 * 8 * 8 * sizeof(float))); // [NO][2 planes][8 tracks][64 units]
 
     // ---- W_hh fragments of the wave's two M tiles: lane (i = l & 15, q) holds gate column 16 mt + i (unit 4 mt + i / 4, gate i % 4), k = 32 ks + 8 q + j
     f16x8 Wf[2][NKS];
@@ -114,6 +118,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
 
     // ---- per octet: this lane's cell, its rows, the granule area
     bool on[NO], lane_on[NO], p_on[NO];
+    unsigned mask8s[NO];
     float c[NO], hlast[NO];
     unsigned plast[NO]; // the fp16 planes of hlast (h1 | h2 << 16)
     float4 p4n[NO];
@@ -130,6 +135,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
         lane0[o] = a.lane_base + LSTM8_TRACKS * octet;
         const unsigned mask8 = (unsigned)(a.lane_mask >> lane0[o]) & 0xffu;
         on[o] = mask8 != 0u;
+        mask8s[o] = mask8;
         lane_on[o] = (mask8 >> tr) & 1u;
         p_on[o] = (mask8 >> p_tr) & 1u;
         const size_t st = (size_t)(lane0[o] + tr) * a.state_stride;
@@ -177,6 +183,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
     // issued during a turn, and the wait in front of their check does not include these stores' acknowledgements.
     const __amdgpu_buffer_rsrc_t rs_rs =
         __builtin_amdgcn_make_buffer_rsrc(a.rs_dir[target], 0, a.rs_dir[target] ? (int)((size_t)2 * a.rs_rows * 4) : 0, 0x00020000);
+    const bool rs_wave = shard == 0 && w == 0, have_planes = a.planes[target] != nullptr;
     const bool both_on = NO == 2 && on[0] && on[NO - 1]; // the turns overlap each other's hand-off only if there are two
     __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): weights, bias, state have arrived (no "wait for everything" inside the loop)
     const bool prof = a.prof != nullptr && octet0 == 0 && chain == 0 && shard == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
@@ -279,7 +286,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 const size_t fr = (size_t)(dir == 0 ? step - 1 : T - step);
                 if (!plp[o] || a.write_f32)
                     outp[o][fr * ldo] = hlast[o]; // lstm.cpp:163-164,170-171
-                if (plp[o])
+                if (plp[o] && !LSTM8_STAGE_PLANES)
                 {
                     plp[o][fr * ldpl] = (unsigned short)(plast[o] & 0xffffu);
                     plp[o][plane_elems + fr * ldpl] = (unsigned short)(plast[o] >> 16);
@@ -295,6 +302,20 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 return;
             if (prof)
                 c2 = clock64();
+            // the PREVIOUS step's row of the fused A planes: staged in LDS by the gate lanes (two bytes each), it leaves as ONE 16-byte store
+            // per lane of two waves -- a whole 128-byte line per (track, plane) -- instead of two 2-byte stores per lane of all eight:
+            // 2 instead of 16 instructions per turn on the CU's one address path
+            if (LSTM8_STAGE_PLANES && !(LSTM8_EXPERIMENT & 2) && have_planes && step > t_begin && w < 2)
+            {
+                const int strk = l >> 3, sgrp = l & 7;
+                if ((mask8s[o] >> strk) & 1u)
+                {
+                    const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((o * 2 + w) * 8 + strk) * LSTM8_UNITS + sgrp * 8);
+                    unsigned short *dst = a.planes[target] + (size_t)w * plane_elems + ((size_t)(lane0[o] + strk) * a.Tp + (size_t)(dir == 0 ? step - 1 : T - step)) * ldpl +
+                                          a.col0 + dir * HL + shard * LSTM8_UNITS + sgrp * 8;
+                    *reinterpret_cast<uint4 *>(dst) = val;
+                }
+            }
             // the next turn's polls: the other octet's granules were published a turn ago
             const int no = NO - 1 - o, nstep = o + 1 < NO ? step : step + 1;
             const bool issue_next = NO > 1 && both_on && nstep > t_begin && nstep < t_end;
@@ -340,8 +361,9 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 const float hp8[8] = {ha.x, ha.y, ha.z, ha.w, hc.x, hc.y, hc.z, hc.w};
                 const float Hs = tree_sum<8>(hp8);
                 // the row that this step multiplied with (step 0 multiplies with the carried state, not a row)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Hs * (1.0f / 16384.0f)), rs_rs,
-                                                      (rs_off[o] != LSTM8_OOR && step > 0) ? rs_off[o] + (dir == 0 ? step - 1 : T - step) * 4 : LSTM8_OOR, 0, 0);
+                if (rs_wave) // (wave-uniform: one wave of a chain)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Hs * (1.0f / 16384.0f)), rs_rs,
+                                                          (rs_off[o] != LSTM8_OOR && step > 0) ? rs_off[o] + (dir == 0 ? step - 1 : T - step) * 4 : LSTM8_OOR, 0, 0);
                 const float hterm = wof2 * Hs;
                 float s[4];
 #pragma unroll
@@ -382,6 +404,12 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                     c[o] = c_t;
                     hlast[o] = h;
                     plast[o] = mine12;
+                }
+                if (LSTM8_STAGE_PLANES && have_planes)
+                {
+                    unsigned short *sg = stg + (o * 2 * 8 + tr) * LSTM8_UNITS + w * 8 + tile * 4 + q;
+                    sg[0] = (unsigned short)b1;
+                    sg[8 * LSTM8_UNITS] = (unsigned short)b2;
                 }
                 // the even unit of a pair publishes it (this unit, the next), tagged step + 1
                 granule_store16<FAST>(gran_rs[o], (lane_on[o] && (q & 1) == 0) ? (step & 1) * gslot + pub_off : LSTM8_OOR,
