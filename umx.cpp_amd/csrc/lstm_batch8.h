@@ -7,8 +7,8 @@
 //
 // Here a workgroup serves an OCTET of 8 lanes and owns 64 hidden units = 256 gate columns of its chain; a chain of a 32-lane
 // launch is 8 column shards x 4 octets = 32 workgroups as before (one per CU, 256 in all), but
-//   * a workgroup needs h of its own 8 lanes only: 512 units x 8 lanes = 2,048 granules = 32 KB per step, and a granule is read by
-//     8 workgroups instead of 16: a quarter of lstm_batch2.h's hand-off bytes, half of lstm_batchs_kernel's;
+//   * a workgroup needs h of its own 8 lanes only: 512 units x 8 lanes = 2,048 granules per step (12 of a granule's 16 bytes are
+//     loaded: 24 KB), and a granule is read by 8 workgroups instead of 16: under half of lstm_batchs_kernel's hand-off bytes;
 //   * the matrix instruction's N = 16 is 8 lanes x the TWO fp16 planes of h * 2^14, so one v_mfma_f32_16x16x32_f16 multiplies both
 //     planes; a wave owns 8 units = 32 gate columns = two M tiles for the WHOLE contraction (W_hh: 2 x 16 fragments = 128 VGPRs for
 //     the layer), so its accumulators ARE the gate pre-activations: no partial sums, no second hand-over of 80 KB through LDS;
@@ -21,6 +21,8 @@
 // accumulator per k-range there): a context uses one form or the other for every launch (engine_lstm.h), so a lane's result
 // still never depends on which other lanes ride along; the same kernel one step per launch is its bit-identical per-step driver.
 // Gate phase: every lane finishes ONE cell -- lanes n < 8 the unit of tile 0, lanes n >= 8 of tile 1 -- 64 cells per wave.
+// What a step costs NOW is the CU's one vector-memory address path: the instruction count per step is what the
+// structure below minimises -- 12-byte polls, the output row's planes staged in LDS and stored by two waves, row sums by one.
 // Hand-off protocol, census, tags, bounded spins, fused A planes / row sums of the consuming GEMM: lstm_batch.h's.
 #pragma once
 #include "lstm_batch.h"
@@ -43,8 +45,8 @@ __host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (
 // NO = octets a workgroup serves IN TURN (2: launches of 33 .. 64 lanes -- octet o and octet o + 4 with the same weight fragments).
 // A step of one octet is a dependent chain  publication -> L2 -> polls (a round of loads ~1,100 cycles + ~700 until the last wave's
 // have come through the CU's one path) -> matrix phase -> gate phase, of which only the last two keep the workgroup's pipes busy
-// (profiles/r05_lstm_batch8_first.txt).  With two octets the polls of the NEXT turn are issued behind the barrier of the current one
-// -- its granules were published a whole turn ago -- and checked when that turn begins: the hand-off of one octet runs under the
+// (profiles/r05_lstm_batch8_first.txt).  With two octets the polls of the NEXT turn are issued inside the matrix phase of the current
+// one -- its granules were published a whole turn ago -- and checked when that turn begins: the hand-off of one octet runs under the
 // matrix and gate phases of the other.  Per (unit, lane) the arithmetic does not know about turns: the bits of NO = 1.
 #ifndef LSTM8_EARLY_KS
 #define LSTM8_EARLY_KS 13 // the next turn's polls are issued behind this k-step of the matrix phase (-1: in front of it)
@@ -56,7 +58,7 @@ __host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (
 #define LSTM8_STAGE_PLANES 1 // the row's fused A planes go through LDS and leave as two 16-byte store instructions per turn (0: two 2-byte stores per lane)
 #endif
 #ifndef LSTM8_FRAG_AHEAD
-#define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions
+#define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions (2 / 4 / 8: the compiler's schedule, and the time, are the same)
 #endif
 template <int HL, bool FAST, bool PRECISE, int NO>
 __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int shard, int octet0, unsigned char *smem, int *abort_flag)
