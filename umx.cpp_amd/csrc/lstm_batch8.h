@@ -58,7 +58,8 @@ __host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (
 #define LSTM8_STAGE_PLANES 1 // the row's fused A planes go through LDS and leave as two 16-byte store instructions per turn (0: two 2-byte stores per lane)
 #endif
 #ifndef LSTM8_FRAG_AHEAD
-#define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions (2 / 4 / 8: the compiler's schedule, and the time, are the same)
+#define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions (2 / 4 / 8: the compiler's schedule, and the time, are the same;
+                           // forcing the read-ahead into the schedule with sched_group_barrier: matrix phase 1,655 -> 1,790-1,860 cycles)
 #endif
 template <int HL, bool FAST, bool PRECISE, int NO>
 __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int shard, int octet0, unsigned char *smem, int *abort_flag)
