@@ -57,6 +57,9 @@ __host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (
 #ifndef LSTM8_STAGE_PLANES
 #define LSTM8_STAGE_PLANES 1 // the row's fused A planes go through LDS and leave as two 16-byte store instructions per turn (0: two 2-byte stores per lane)
 #endif
+#ifndef LSTM8_PIN_ORDER
+#define LSTM8_PIN_ORDER 1 // the matrix phase in the order written (sched_barrier): two matrix instructions, then the fragment read LSTM8_FRAG_AHEAD k-steps ahead -- left to itself the scheduler sinks every read to its use (1,655 -> 1,540 cycles)
+#endif
 #ifndef LSTM8_FRAG_AHEAD
 #define LSTM8_FRAG_AHEAD 4 // h fragments a wave reads ahead of its matrix instructions (2 / 4 / 8: the compiler's schedule, and the time, are the same;
                            // forcing the read-ahead into the schedule with sched_group_barrier: matrix phase 1,655 -> 1,790-1,860 cycles)
@@ -332,6 +335,8 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
 #pragma unroll
             for (int i = 0; i < LSTM8_FRAG_AHEAD; ++i)
                 bf[i] = *reinterpret_cast<const f16x8 *>(fb + i * 1024);
+            if (LSTM8_PIN_ORDER)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < KSW; ++kk)
                 accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones16, *reinterpret_cast<const f16x8 *>(fb + (w * KSW + kk) * 1024), accH, 0, 0, 0);
@@ -344,6 +349,8 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[1][ks], cur, acc1, 0, 0, 0);
                 if (ks + LSTM8_FRAG_AHEAD < NKS)
                     bf[ks % LSTM8_FRAG_AHEAD] = *reinterpret_cast<const f16x8 *>(fb + (ks + LSTM8_FRAG_AHEAD) * 1024);
+                if (LSTM8_PIN_ORDER)
+                    __builtin_amdgcn_sched_barrier(0); // the order as written: two matrix instructions, the read LSTM8_FRAG_AHEAD k-steps ahead
                 if (ks == 3) // (every row of accH holds the same sums; column n: plane n / 8 of track n % 8)
                     hs[tr * 8 + w] = accH[0] + __int_as_float(dpp_row_ror<8>(__float_as_int(accH[0])));
                 if (NO > 1 && ks == (LSTM8_EARLY_KS < 0 ? 0 : LSTM8_EARLY_KS))
