@@ -40,10 +40,7 @@ constexpr int LSTM8_OCTETS = 4;  // octets of a launch: 32 lanes
 __host__ __device__ inline size_t lstm8_granule_bytes(int Hl) { return (size_t)2 * 8 * (Hl / 2) * LSTM8_TRACKS * 16; }
 // LDS: h in fragment order [2 steps][Hl / 32 k-steps][4 k-groups][16 n] x 16 B, the eight k-range sums of h' [2][8 tracks][8 waves]
 __host__ __device__ inline size_t lstm8_h_bytes(int Hl) { return (size_t)(Hl / 32) * 4 * 16 * 16; }
-#ifndef LSTM8_KHALVES
-#define LSTM8_KHALVES 0 // 1: the contraction split over pairs of waves (lstm8_body; + 16 KB of LDS per octet for the partial sums)
-#endif
-__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float) + 2 * 8 * LSTM8_UNITS * 2 + (LSTM8_KHALVES ? 8 * 2 * 64 * 16 : 0)); } // no: octets per workgroup; + the row's planes staged for their store
+__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float) + 2 * 8 * LSTM8_UNITS * 2); } // no: octets per workgroup; + the row's planes staged for their store
 
 // NO = octets a workgroup serves IN TURN (2: launches of 33 .. 64 lanes -- octet o and octet o + 4 with the same weight fragments).
 // A step of one octet is a dependent chain  publication -> L2 -> polls (a round of loads ~1,100 cycles + ~700 until the last wave's
@@ -87,40 +84,6 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
     unsigned short *const stg = reinterpret_cast<unsigned short *>(smem + (size_t)NO * (2 * HB + 2 * 8 * 8 * sizeof(float))); // [NO][2 planes][8 tracks][64 units]
 
     // ---- W_hh fragments of the wave's two M tiles: lane (i = l & 15, q) holds gate column 16 mt + i (unit 4 mt + i / 4, gate i % 4), k = 32 ks + 8 q + j
-#if LSTM8_KHALVES
-    // The contraction split over PAIRS of waves (the matrix phase is bound by its LDS fragment reads): wave w multiplies
-    // its own two M tiles (mt = 0, 1: units 8 w + 4 mt + ..) AND its partner's (mt = 2, 3: units 8 (w ^ 1) + ..) over HALF of the k-steps
-    // (half w & 1), hands the partner's partial sums over through LDS and finishes its own: half the fragment reads per wave for the same
-    // 128 registers of weights and the same 32 matrix instructions.  (Round 5: built, GPU suite of tests/test_gpu_batch.py green and A/B'd
-    // with the scheduler's instruction order -- no gain; re-created behind this switch after the order was pinned, compile-checked only.)
-    constexpr int MTW = 4, NKW = NKS / 2;
-    const int kh = w & 1, ks0 = kh * NKW; // this wave's k-steps: ks0 .. ks0 + NKW - 1
-    f16x8 Wf[MTW][NKW];
-    {
-        const unsigned char *wp[MTW];
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-        {
-            const int ug = shard * LSTM8_UNITS + (mt < 2 ? w : (w ^ 1)) * 8 + (mt & 1) * 4 + (n >> 2);
-            wp[mt] = a.Wq + (((size_t)wchain * S + (ug >> 4)) * HL + 32 * ks0 + 8 * q) * 64 + 4 * (ug & 15) + (n & 3);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NKW; ++ks)
-        {
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-            {
-                f16x8 hw;
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    hw[j] = (_Float16)((float)wp[mt][(size_t)(32 * ks + j) * 64] - 128.0f);
-                Wf[mt][ks] = hw;
-            }
-            asm volatile("" ::: "memory");
-        }
-    }
-    float4 *const xch = reinterpret_cast<float4 *>(smem + (size_t)NO * (2 * HB + 2 * 8 * 8 * sizeof(float) + 2 * 8 * LSTM8_UNITS * 2)); // [NO][8 waves][2 tiles][64 lanes]
-#else
     f16x8 Wf[2][NKS];
     {
         const unsigned char *wp[2];
@@ -145,7 +108,6 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
             asm volatile("" ::: "memory"); // (sixteen byte loads in flight, not 256)
         }
     }
-#endif
     constexpr float HSCALE = 16384.0f;
     const float wsc = a.wsc[wchain] * (1.0f / HSCALE), wof2 = (a.wof[wchain] + 128.0f * a.wsc[wchain]) * (1.0f / HSCALE);
     const float4 bh = *reinterpret_cast<const float4 *>(a.bhh + ((size_t)wchain * S + (U >> 4)) * 64 + 4 * (U & 15));
@@ -368,56 +330,6 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
             // track -- and the next turn's polls are loads every lane issues, out of range where there is nothing to poll), fragments
             // read LSTM8_FRAG_AHEAD k-steps ahead of the products that take them
             const unsigned char *const fb = hb + (q * 16 + n) * 16;
-#if LSTM8_KHALVES
-            floatx4 accH = {0.f, 0.f, 0.f, 0.f}, acc[MTW];
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-                acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-            const unsigned char *const fbw = fb + ks0 * 1024; // this wave's k-steps
-            f16x8 bf[LSTM8_FRAG_AHEAD];
-#pragma unroll
-            for (int i = 0; i < LSTM8_FRAG_AHEAD; ++i)
-                bf[i] = *reinterpret_cast<const f16x8 *>(fbw + i * 1024);
-            if (LSTM8_PIN_ORDER)
-                __builtin_amdgcn_sched_barrier(0);
-            const int hr = kh * 4 + (w >> 1); // the sum of h' over k-range hr = the two k-steps 2 hr, 2 hr + 1, inside this wave's half
-#pragma unroll
-            for (int kk = 0; kk < KSW; ++kk)
-                accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones16, *reinterpret_cast<const f16x8 *>(fb + (hr * KSW + kk) * 1024), accH, 0, 0, 0);
-            const int poll_base = (NO > 1 && issue_next && p_on[no]) ? ((nstep - 1) & 1) * gslot + goff0 : LSTM8_OOR;
-#pragma unroll
-            for (int ks = 0; ks < NKW; ++ks)
-            {
-                const f16x8 cur = bf[ks % LSTM8_FRAG_AHEAD];
-#pragma unroll
-                for (int mt = 0; mt < MTW; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[mt][ks], cur, acc[mt], 0, 0, 0);
-                if (ks + LSTM8_FRAG_AHEAD < NKW)
-                    bf[ks % LSTM8_FRAG_AHEAD] = *reinterpret_cast<const f16x8 *>(fbw + (ks + LSTM8_FRAG_AHEAD) * 1024);
-                if (LSTM8_PIN_ORDER)
-                    __builtin_amdgcn_sched_barrier(0);
-                if (ks == 2)
-                    hs[tr * 8 + hr] = accH[0] + __int_as_float(dpp_row_ror<8>(__float_as_int(accH[0])));
-                if (NO > 1 && ks == (LSTM8_EARLY_KS < 0 ? 0 : LSTM8_EARLY_KS / 2))
-                {
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i)
-                        v[i] = __builtin_amdgcn_raw_buffer_load_b96(gran_rs[no], poll_base == LSTM8_OOR ? LSTM8_OOR : poll_base + i * 512 * 16, 0, 16); // sc1
-                    pending = issue_next;
-                }
-            }
-            // the partner finishes tiles 2, 3; this wave's own tiles get the partner's half behind the barrier (k in ascending order: low + high)
-            xch[((o * 8 + w) * 2 + 0) * 64 + l] = make_float4(acc[2][0], acc[2][1], acc[2][2], acc[2][3]);
-            xch[((o * 8 + w) * 2 + 1) * 64 + l] = make_float4(acc[3][0], acc[3][1], acc[3][2], acc[3][3]);
-            floatx4 acc0 = acc[0], acc1 = acc[1];
-            LSTM8_LDS_BARRIER(); // the eight k-range sums of h' and the partners' partial sums are in LDS
-            {
-                const float4 t0 = xch[((o * 8 + (w ^ 1)) * 2 + 0) * 64 + l], t1 = xch[((o * 8 + (w ^ 1)) * 2 + 1) * 64 + l];
-                const floatx4 p0 = {t0.x, t0.y, t0.z, t0.w}, p1 = {t1.x, t1.y, t1.z, t1.w};
-                acc0 = kh ? p0 + acc0 : acc0 + p0;
-                acc1 = kh ? p1 + acc1 : acc1 + p1;
-            }
-#else
             floatx4 accH = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             f16x8 bf[LSTM8_FRAG_AHEAD];
 #pragma unroll
@@ -450,7 +362,6 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 }
             }
             LSTM8_LDS_BARRIER(); // the eight k-range sums of h' are in LDS
-#endif
             if (prof)
                 c3 = clock64();
 
