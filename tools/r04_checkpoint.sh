@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4: the evidence of a build -- GPU suite, bench line, rocprofv3 kernel stats + FETCH/WRITE, SQ counters, accuracy table
+# the evidence of a build (rounds 4-5: tools/r04_checkpoint.sh <tag>) -- GPU suite, bench line at the default 64 lanes, rocprofv3 kernel
+# stats + FETCH/WRITE of the same command, SQ counters of the GEMM / recurrence kernels at 32 lanes, accuracy table; ~19 GPU-minutes
 tag=${1:-r04_v2}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
