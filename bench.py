@@ -149,7 +149,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="sync after every step (no cross-segment pipelining)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the value_pcie leg")
     ap.add_argument("--no-single-track", action="store_true", help="skip the single-track (tracks = 1) leg")
-    ap.add_argument("--track-seconds", type=float, default=0.0,
+    ap.add_argument("--track-seconds", type=float, default=600.0,
                     help="also time a whole track of this length through umx_hip_shift_inference (host buffers in and "
                          "out, PCIe included; BASELINE config 4 on one GPU) and report it as 'track'")
     ap.add_argument("--mode", choices=["segments", "track", "targets"], default="segments",
@@ -251,6 +251,7 @@ def main():
     finite = bool(all(torch.isfinite(o).all().item() for st_ in out_sets for o in st_))
     lstm_mode, batched = eng.lstm_mode(), eng.lstm_is_batched()
     lstm_kernel = eng.lstm_kernel_name()  # what the engine launched, not a guess from the lane count
+    gemm_kernels = [eng.gemm_kernel_name(m) for m in range(4)]  # per stage: fc1, W_ih, fc2, fc3
 
     # ---- value_pcie: pinned host buffers in and out, the same number of steps timed the same way
     dt_pcie = None
@@ -441,20 +442,18 @@ def main():
                     "algorithmic_TFLOPs_alone": round(alg / (ms_alone * 1e-3) / 1e12, 1) if ms_alone > 0 else None,
                     "traffic": find_traffic(*tneedles)}
         planes = flavour in ("planes", "bf16x3")  # both run on the bf16 matrix cores
-        gname = "gemm_planes_kernel" if flavour == "planes" else "gemm_bf16x3_kernel" if flavour == "bf16x3" else "gemm_tn_kernel"
         exact = planes and not args.expanded_weights and not args.u8_dequant  # integer weights as exact bf16 terms
         # products per fp32 product: planes = 2 fp16 planes per activation x 1 weight plane (u8), or 3 of the 4 products with the 2 (u16 / fp32);
         # bf16x3 = 3 bf16 terms per activation x 1 exact plane (u8) or the 6-product rule
         p8 = (2 if exact else 4) if flavour == "planes" else (3 if exact else 6)
         p16 = 3 if flavour == "planes" else 6  # (a2 x the low weight plane, 2^-22 of the sum, is not formed: csrc/gemm_planes.h)
-        # (the PMC summary holds demangled names: "void umx::gemm_planes_kernel<1, 1, 4, 4>(umx::GemmPArgs)" = <MODE, planes of B, WM, WN>)
-        # 256 x 256 launches run the ping-pong form of the plane GEMM (csrc/gemm_planes_pp.h), unless UMX_GEMM_PP says otherwise
-        pp = flavour == "planes" and os.environ.get("UMX_GEMM_PP") is None and B * T >= 4096
-        g8 = "gemm_planes_pp_kernel" if pp else gname
-        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{g8}<G_FC1>", (g8 + "<0,",)),
-                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{g8}<G_IH>", (g8 + "<1,",)),
-                   gemm_entry(["fc2"], "fc2", p16, f"{g8}<G_FC2>", (g8 + "<2,",)),
-                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{g8}<G_FC3>", (g8 + "<3,",))]
+        # (the PMC summary holds demangled names: "void umx::gemm_planes_ps_kernel<1, 1>(umx::GemmPArgs, int)" = <MODE, planes of B>);
+        # which kernel served a stage is what the engine reports (persistent walk gemm_planes_ps_kernel for launches with more 256 x 256
+        # tiles than CUs, else gemm_planes_pp_kernel / gemm_planes_kernel; gemm_bf16x3_kernel in one-track contexts)
+        kernels = [gemm_entry(["fc1"], "fc1", p8, f"{gemm_kernels[0]}<G_FC1>", (gemm_kernels[0] + "<0,",)),
+                   gemm_entry(["lstm_ih0", "lstm_ih1", "lstm_ih2"], "lstm_ih", p8, f"{gemm_kernels[1]}<G_IH>", (gemm_kernels[1] + "<1,",)),
+                   gemm_entry(["fc2"], "fc2", p16, f"{gemm_kernels[2]}<G_FC2>", (gemm_kernels[2] + "<2,",)),
+                   gemm_entry(["fc3_mask"], "fc3_mask", p16, f"{gemm_kernels[3]}<G_FC3>", (gemm_kernels[3] + "<3,",))]
         lstm_keys = [f"lstm_rec{l}" for l in range(3)]
         lms = sum(stage_ms.get(kk, 0.0) for kk in lstm_keys) / 3
         lms_alone = sum(stage_alone_ms.get(kk, 0.0) for kk in lstm_keys) / 3

@@ -47,6 +47,12 @@ extern "C" {
 #define UMX_FLAG_LSTM_PROFILE 0x80  /* persistent kernel: record per-phase cycle counters */
 #define UMX_FLAG_DEBUG_LSTM_ABORT 0x2000 /* testing: the persistent LSTM launch of layer 1 gives up half way, exactly as if a
                                           hidden-state poll had timed out (exercises the recovery of umx_hip_sync) */
+#define UMX_FLAG_RESET_SEGMENTS 0x4000 /* umx_hip_split_inference / _shift_inference / _separate_tracks with ONE track on a context made by
+                                        * umx_hip_create_tracks: RESET MODE -- every segment starts from a zero lstm_data instead of the one its
+                                        * predecessor left (umx.cpp:167-171 creates it once per track, :226-227 passes it to every segment): a
+                                        * DECLARED deviation from the reference, opt-in.  The track's segments are then independent and ride as
+                                        * the track lanes of one call (a 600 s track = 14 lanes of one pass).  Equals split_inference with
+                                        * umx_lstm_set_zero (lstm.cpp:86-99) in front of every segment. */
 #define UMX_FLAG_PRECISE_ACT 0x1000 /* LSTM gates with the device-library expf/tanhf + IEEE division instead of
                                        the hardware v_exp_f32 / v_rcp_f32 forms (~1e-7 abs difference) */
 
@@ -319,6 +325,9 @@ int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);
  * "lstm_batch8_kernel" (track-batched, hidden 1024), "lstm_batch_kernel" / "lstm_batchs_kernel" / "lstm_batcht_kernel" /
  * "lstm_batch2_kernel" (the forms of csrc/lstm_batch.h, lstm_batch2.h). */
 const char *umx_hip_lstm_kernel_name(const umx_hip_ctx *ctx);
+/* The GEMM kernel the last call launched for stage `mode` (0 fc1, 1 W_ih, 2 fc2, 3 fc3): "gemm_planes_ps_kernel" (persistent walk),
+   "gemm_planes_pp_kernel", "gemm_planes_kernel", "gemm_bf16x3_kernel" or "none".  For bench.py's per-kernel figures: no reference analogue. */
+const char *umx_hip_gemm_kernel_name(const umx_hip_ctx *ctx, int mode);
 /* 0 = per-timestep driver, 1 = persistent kernel with the placement-independent (sc1) hand-off,
  * 2 = persistent kernel whose census found every chain on one XCD (intra-L2 hand-off); < 0 on error */
 int umx_hip_lstm_mode(umx_hip_ctx *ctx);

@@ -144,6 +144,38 @@ def test_ping_pong_gemm_gives_the_bits_of_the_lock_step_kernel(pkg, tmp_path, mo
             assert (res[pp][1][b] == res["15"][1][b]).all(), (pp, b)
 
 
+def test_persistent_gemm_gives_the_bits_of_the_ping_pong_kernel(pkg, tmp_path, monkeypatch):
+    """csrc/gemm_planes_ps.h (round 6: one workgroup per CU walks the tiles of all four targets, a tile's epilogue inside the first
+    trip of the next tile, tables of row / column vectors in LDS) against csrc/gemm_planes_pp.h (one tile per workgroup): every
+    accumulator sees the same matrix instructions in the same order and every element the same scalar epilogue, so stems, carried
+    state and the mask tap agree bit for bit -- with the persistent kernel on all four GEMMs, on none, and as shipped.  16 lanes x 900
+    frames, hidden 512: more 256 x 256 tiles than CUs in every GEMM, tiles that straddle two lanes and the M padding in fc3."""
+    H, N, B = 512, 900 * 1024, 16
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=53), H, compress=False)
+    waves = [[pkg.ggml.synth_audio(N - 333 * b, 1500 + 10 * b + s) for b in range(B)] for s in range(2)]
+    res = {}
+    for ps in ("15", "0", None):
+        if ps is None:
+            monkeypatch.delenv("UMX_GEMM_PS", raising=False)
+        else:
+            monkeypatch.setenv("UMX_GEMM_PS", ps)
+        eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
+        outs = [eng.infer_batch(w, pkg.FLAG_DEBUG_TAPS) for w in waves]
+        taps = {f"{name}#{b}": eng.tap(f"{name}#{b}", 3) for b in (0, B - 1) for name in ("fc1", "fc2", "mask")}
+        res[ps] = (outs, [eng.track_stream_get(b) for b in range(B)], taps)
+        eng.close()
+    for ps in ("0", None):
+        for k, v in res["15"][2].items():
+            assert (res[ps][2][k] == v).all(), (ps, k)
+        for s in range(2):
+            for b in range(B):
+                for t in range(4):
+                    assert (res[ps][0][s][b][t] == res["15"][0][s][b][t]).all(), (ps, s, b, t)
+        for b in range(B):
+            assert (res[ps][1][b] == res["15"][1][b]).all(), (ps, b)
+
+
 def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, monkeypatch):
     """17 .. 32 lanes, hidden 1024: csrc/lstm_batch.h's lstm_batchs_kernel (round 4: the two groups of 16 lanes side by side on the chip,
     every chain 16 workgroups of two slices -- half the hand-off bytes per step) against csrc/lstm_batch2.h (the groups in turn through
@@ -268,8 +300,8 @@ def test_production_configuration_at_full_size_against_the_oracle(pkg, po, tmp_p
 @pytest.mark.parametrize("B", [32, 48, 64])
 def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path, B):
     """what `bench.py` times by default -- 32 (and 48) track lanes x the full 60 s segment
-    (T = 2584) through lstm_batch2_kernel (groups of 16 lanes in turn: ring refills over 2,584 steps, 128-144 KB of LDS)
-    and plane-GEMM launches of 82,688 (124,032) rows -- against the ORACLE, not only `outputs_finite`.  Two distinct tracks
+    (T = 2584) through lstm_batch8_kernel (octets of 8 lanes x column shards of 64 units; more than 32 lanes: two octets per workgroup
+    in turn) and plane-GEMM launches of 82,688 (124,032 / 165,376) rows -- against the ORACLE, not only `outputs_finite`.  Two distinct tracks
     duplicated over the lanes: a lane of the first and a lane of the second group (0 and 17; 40 of the third for B = 48)
     against the oracle on every stage tap, the stems and the carried state; every duplicate bitwise equal to its original;
     and bitwise equal to the same track in a 3-lane context (one group: lstm_batch_kernel)."""
@@ -309,7 +341,17 @@ def test_the_bench_configuration_is_value_checked_at_full_size(pkg, po, tmp_path
         for t in range(4):
             assert (got[b][t] == got[first[k]][t]).all(), (B, b, t)
     keep = {k: ([got[first[k]][t].copy() for t in range(4)], states[k]) for k in (0, 1)}
-    del got
+    # the instruction stream bench.py times: the same call WITHOUT the debug taps (the recurrence then writes the next GEMM's planes
+    # only, no fp32 rows) -- stems and carried state against the oracle, and the bits of the tapped call
+    eng.track_stream_reset(-1)
+    plain = eng.infer_batch([tracks[which[i]] for i in range(B)])
+    for b in checked:
+        ref, taps, st = refs[which[b]]
+        for t in range(4):
+            assert float(np.abs(plain[b][t] - ref[t]).max()) < REG_WAVE, ("no taps", B, b, t)
+            assert (plain[b][t] == got[b][t]).all(), ("no taps", B, b, t)
+        assert rel_l2(eng.track_stream_get(b), st) < REG_STAGE, ("no taps", B, b)
+    del got, plain
     eng.close()
     small = pkg.Engine.from_file(path, N, tracks=3)
     g3 = small.infer_batch([tracks[1], tracks[0], tracks[1]])
@@ -344,6 +386,45 @@ def test_batched_kernel_agrees_with_single_track_kernel(pkg, tmp_path):
         for t in range(4):
             assert (b[s][0][t] == b[s][1][t]).all()  # two lanes fed the same audio: same bits
             assert np.abs(b[s][1][t] - a[s][t]).max() < 1e-5
+
+
+def test_reset_mode_runs_the_segments_of_one_track_as_lanes(pkg, po, model_small):
+    """UMX_FLAG_RESET_SEGMENTS (SURVEY 8(e) mode table; a declared deviation from umx.cpp:167-171,226-227): every segment of a track
+    from a zero lstm_data, the segments as the track lanes of one call (here 4 lanes: a 6-segment track takes two passes).  Against
+    the ORACLE run segment by segment from a zero state (lstm.cpp:86-99 in front of every umx_inference) through the C++ host
+    driver's overlap-add, bit for bit against the same engine fed one segment at a time from a reset state, and different from the
+    default (carry) mode, which is unchanged."""
+    path, om, targets = model_small
+    N = 16 * 1024
+    wave = pkg.ggml.synth_audio(int(N * 4.3), 77)
+    eng = pkg.Engine(targets, 128, N, tracks=4)
+
+    def oracle_seg(w):
+        return po.umx_inference(om, w, n_buf=N, state=po.stream_state(128))[0]
+
+    def engine_seg(w):
+        eng.track_stream_reset(-1)
+        return eng.infer_batch([w])[0]
+    for shift in (None, 4033):
+        run = (lambda be: pkg.split_inference(be, wave, N)) if shift is None else (lambda be: pkg.shift_inference(be, wave, N, offset=shift))
+        ref = run(pkg.make_backend(oracle_seg))
+        one = run(pkg.make_backend(engine_seg))
+        carry = eng.separate(wave, shift_offset=shift)
+        got = eng.separate(wave, flags=pkg.FLAG_RESET_SEGMENTS, shift_offset=shift)
+        again = eng.separate(wave, shift_offset=shift)
+        for t in range(4):
+            assert float(np.abs(got[t] - ref[t]).max()) < TOL_WAVE, (shift, t)
+            assert (got[t] == one[t]).all(), (shift, t)
+            assert (again[t] == carry[t]).all(), (shift, t)      # the default mode is what it was
+        assert max(float(np.abs(got[t] - carry[t]).max()) for t in range(4)) > 0  # ... and is not reset mode
+    # one track only, and only on a track-batched context
+    with pytest.raises(RuntimeError):
+        eng.separate_many([wave, wave], flags=pkg.FLAG_RESET_SEGMENTS)
+    eng.close()
+    single = pkg.Engine(targets, 128, N)
+    with pytest.raises(RuntimeError):
+        single.separate(wave, flags=pkg.FLAG_RESET_SEGMENTS)
+    single.close()
 
 
 def test_idle_lane_keeps_its_state_and_lanes_reset_independently(pkg, model_small):

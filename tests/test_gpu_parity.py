@@ -342,7 +342,8 @@ def test_wiener_bin_arithmetic_against_a_reference_order_float64_restatement(pkg
     reference's (v_j R_j Cxx^-1) x.  Here the device functions run on given bins (umx_hip_debug_wiener_bins) against numpy
     float64 in the REFERENCE's operation order (wiener.cpp:187-202 PSD with F5, :301-325 Cxx with the 4x regularisation F6,
     :54-84 inverse, :339-376 gain, :381-400 apply, :408-422 rescale): well-conditioned bins to 1e-5 of the bin's largest output, all-zero
-    masks (Cxx = 4 sqrt(eps) I, v = 0: exact zeros), a silent mixture bin (arg 0 = 0), and NaN in -> NaN out without touching its neighbours."""
+    masks (Cxx = 4 sqrt(eps) I, v = 0: exact zeros), a silent mixture bin (arg 0 = 0), a near-silent one (1e-20: below the range in which
+    sqrt(re^2 + im^2) is accurate, treated as silent), and NaN in -> NaN out without touching its neighbours."""
     import ctypes as C
     rng = np.random.default_rng(5)
     n = 4096
@@ -354,6 +355,7 @@ def test_wiener_bin_arithmetic_against_a_reference_order_float64_restatement(pkg
     masks[0] = 0.0          # nothing of any source in this bin
     X[1] = 0.0              # a silent mixture bin
     X[2, 0, 0] = np.nan     # a poisoned bin
+    X[3] = np.float32(1e-20) * np.array([[0.6, -0.8], [-0.28, 0.96]], np.float32)  # a near-silent bin: re^2 + im^2 underflows
     max_abs = np.float32(max(1.0, 30.0 / 10.0))
     y = np.zeros((n, 4, 2, 2), np.float32)
     fp = C.POINTER(C.c_float)
@@ -388,6 +390,9 @@ def test_wiener_bin_arithmetic_against_a_reference_order_float64_restatement(pkg
     assert (got[1] == 0).all() or float(np.abs(got[1]).max()) == 0.0  # x = 0
     assert not np.isfinite(got[2]).all()             # NaN in -> NaN out
     assert np.isfinite(got[3:]).all()
+    # |X| below 1e-18 (common.h: the squares leave the normal range) counts as a silent bin of phase 0: the absolute difference to
+    # the reference's polar(mag, arg X) is of the size of the bin itself
+    assert float(np.abs(got[3] - ref[3]).max()) < 1e-16, np.abs(got[3] - ref[3]).max()
 
 
 def test_gemm_flavours_agree(pkg, po, model_small, tmp_path):

@@ -17,7 +17,7 @@ for v in variants:
         elif v != "default":
             env["UMX_HIP_LIB"] = os.path.abspath(v)
         tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "").replace("env:", "").replace("=", "")
-        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-single-track"] + extra
+        cmd = [sys.executable, "bench.py", "--tracks", str(b), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-single-track", "--track-seconds", "0"] + extra
         if os.environ.get("AB_PROFILE"):  # the in-kernel profiler slows the profiled workgroup, and with it its whole chain
             cmd.append("--lstm-profile")
         if b == 1:

@@ -7,9 +7,9 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python $R/bench.py > $out/bench.json 2> $out/bench.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-single-track > $out/bench_under_rocprof.json 2> $out/trace.err
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-single-track --serial > /dev/null 2> $out/pmc_fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-single-track --serial > /dev/null 2> $out/pmc_write.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-single-track --track-seconds 0 > $out/bench_under_rocprof.json 2> $out/trace.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-single-track --track-seconds 0 --serial > /dev/null 2> $out/pmc_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-single-track --track-seconds 0 --serial > /dev/null 2> $out/pmc_write.err
 cd $R
 python - <<PY
 import csv, glob, collections, os

@@ -9,7 +9,7 @@ for v in variants:
     if v != "default":
         env["UMX_HIP_LIB"] = os.path.abspath(v)
     tag = os.path.basename(v).replace("libumx_hip_", "").replace(".so", "")
-    p = subprocess.run([sys.executable, "bench.py", "--tracks", tracks, "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-single-track"],
+    p = subprocess.run([sys.executable, "bench.py", "--tracks", tracks, "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-pcie", "--no-single-track", "--track-seconds", "0"],
                        env=env, capture_output=True, text=True, timeout=900)
     open(f"{out}/{tag}.json", "w").write(p.stdout)
     open(f"{out}/{tag}.err", "w").write(p.stderr)

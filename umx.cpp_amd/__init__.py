@@ -29,6 +29,7 @@ FLAG_LSTM_FORCE_SAFE = 0x40
 FLAG_LSTM_PROFILE = 0x80
 FLAG_PRECISE_ACT = 0x1000
 FLAG_DEBUG_LSTM_ABORT = 0x2000
+FLAG_RESET_SEGMENTS = 0x4000  # whole-track calls: every segment from a zero LSTM state, segments as lanes of one call (declared deviation)
 
 
 def FLAG_SKIP_TARGET(t):
@@ -124,6 +125,8 @@ def hip_lib():
     lib.umx_hip_debug_wiener_bins.argtypes = [C.c_int, _fp, _fp, _fp, C.c_float, _fp]
     lib.umx_hip_lstm_kernel_name.restype = C.c_char_p
     lib.umx_hip_lstm_kernel_name.argtypes = [C.c_void_p]
+    lib.umx_hip_gemm_kernel_name.restype = C.c_char_p
+    lib.umx_hip_gemm_kernel_name.argtypes = [C.c_void_p, C.c_int]
     lib.umx_hip_debug_lstm_placement.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     lib.umx_hip_stream_layer_floats.restype = C.c_size_t
     lib.umx_hip_stream_layer_floats.argtypes = [C.c_void_p]
@@ -159,7 +162,7 @@ HIP_SYMBOLS = ["umx_hip_create", "umx_hip_create_ex", "umx_hip_create_tracks", "
                "umx_hip_infer_segment_device", "umx_hip_sync", "umx_hip_stream_handle", "umx_hip_nb_frames",
                "umx_hip_segment_samples", "umx_hip_hidden", "umx_hip_read_tap", "umx_hip_stage_times",
                "umx_hip_stage_times_slot", "umx_hip_stage_kernel_times_slot",
-               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_lstm_kernel_name", "umx_hip_debug_wiener_bins", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
+               "umx_hip_lstm_was_persistent", "umx_hip_lstm_mode", "umx_hip_lstm_kernel_name", "umx_hip_gemm_kernel_name", "umx_hip_debug_wiener_bins", "umx_hip_debug_lstm_profile", "umx_hip_debug_lstm_placement",
                "umx_hip_stream_layer_floats", "umx_hip_stream_get_layer", "umx_hip_stream_set_layer",
                "umx_hip_segment_begin", "umx_hip_segment_lstm_layer", "umx_hip_segment_end",
                "umx_hip_split_inference", "umx_hip_shift_inference", "umx_hip_debug_lds_guard", "umx_hip_debug_f16_bits",
@@ -418,6 +421,10 @@ class Engine:
         self._check(self.lib.umx_hip_debug_lstm_profile(self.h, buf))
         a = np.array(buf[:], dtype=np.uint64).reshape(3, 2, 8)
         return a
+
+    def gemm_kernel_name(self, mode):
+        """The GEMM kernel the last call launched for stage `mode` (0 fc1, 1 W_ih, 2 fc2, 3 fc3)."""
+        return self.lib.umx_hip_gemm_kernel_name(self.h, mode).decode()
 
     def lstm_kernel_name(self):
         """The recurrence kernel of the last LSTM layer launch (umx_hip_lstm_kernel_name)."""

@@ -53,14 +53,18 @@ __device__ __forceinline__ float div_by(float a, float b, float rcp_b)
 // (correctly rounded square root of the fp32 sum: within 1.5 ulp of hypotf, which the oracle uses) instead of the device
 // library's hypotf (~25 instructions of scaling the spectrogram's range never needs) -- and the SAME value is the divisor of
 // the unit phasor below, so a bin needs one square root where it took a hypotf, a sqrtf and two IEEE divisions.
+// Valid range: |X| >= ~1e-18 (the squares stay normal fp32 numbers; a 4096-point transform of 16-bit audio has no bin that small
+// unless it is exactly zero); below, the squares are subnormal or zero and the value is a magnitude of the right order at best.
 __device__ __forceinline__ float mix_magnitude(float2 z) { return sqrtf(z.x * z.x + z.y * z.y); }
 // X / |X| (std::polar's phase, wiener.cpp:96-109; arg(0) = 0): the quotients are the correctly rounded ones (div_by: the bits of the
-// IEEE divisions this replaced); |X| below 1e-30 (the squares underflow long before) counts as zero
+// IEEE divisions this replaced).  |X| below 1e-18 -- where mix_magnitude is no longer accurate and the quotients would not be of unit
+// length -- counts as a silent bin (phase 0): a deviation from the reference of the size of the bin itself
+// (tests/test_gpu_parity.py::test_wiener_bin_arithmetic_...: a 1e-20 bin)
 __device__ __forceinline__ float2 unit_phasor(float2 x)
 {
     const float a = mix_magnitude(x);
     const float ra = __builtin_amdgcn_rcpf(a);
-    return a > 1e-30f ? make_float2(div_by(x.x, a, ra), div_by(x.y, a, ra)) : make_float2(1.f, 0.f);
+    return a > 1e-18f ? make_float2(div_by(x.x, a, ra), div_by(x.y, a, ra)) : make_float2(1.f, 0.f);
 }
 // element (channel c, frame f, bin b) of a mask plane [2][T][MAGP]
 __device__ __forceinline__ size_t mask_index(int c, int T, int f, int b) { return ((size_t)c * T + f) * MAGP + b; }

@@ -27,6 +27,7 @@
 #include "gemm_bf16x3.h"
 #include "gemm_planes.h"
 #include "gemm_planes_pp.h"
+#include "gemm_planes_ps.h"
 #include "lstm_kernels.h"
 #include "lstm_batch.h"
 #include "lstm_batch2.h"
@@ -451,7 +452,9 @@ struct umx_hip_ctx
     int recover();
     int lstm_poll_delay = 0;         // 0 = the kernel's default (LSTM_POLL_DELAY)
     bool env_lstm_grouped = true;    // UMX_LSTM_GROUPED (0: 17 .. 32 lanes as groups in turn) and UMX_GEMM_PP (bit mask of the GEMMs that
+    int env_gemm_ps = -1;            // UMX_GEMM_PS: bit per GemmMode, which 256 x 256 launches take the persistent kernel (gemm_planes_ps.h); < 0: all
     int env_gemm_pp = -1;            // take the ping-pong kernel; < 0: all) are read ONCE, when the context is created: a test makes a context per mode
+    const char *gemm_kernel_last[4] = {"none", "none", "none", "none"}; // per GemmMode (umx_hip_gemm_kernel_name)
     const char *lstm_kernel_last = "none"; // the recurrence kernel of the last layer launch (umx_hip_lstm_kernel_name)
     int lstm_threads = LSTM_THREADS; // 512 (two workgroups per CU fit) or 576 (dedicated gate wave)
     int lstm_capacity = 0;           // workgroups of the persistent LSTM kernel that can be co-resident

@@ -743,6 +743,8 @@ int umx_hip_stage_kernel_times_slot(umx_hip_ctx *ctx, int slot_index, float *ms,
 
 const char *umx_hip_lstm_kernel_name(const umx_hip_ctx *ctx) { return ctx ? ctx->lstm_kernel_last : "none"; }
 
+const char *umx_hip_gemm_kernel_name(const umx_hip_ctx *ctx, int mode) { return ctx && mode >= 0 && mode < 4 ? ctx->gemm_kernel_last[mode] : "none"; }
+
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx) { return ctx && ctx->slot[ctx->cur].last_persistent ? 1 : 0; }
 
 int umx_hip_lstm_mode(umx_hip_ctx *ctx)

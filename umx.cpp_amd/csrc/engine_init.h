@@ -168,6 +168,8 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         env_lstm_grouped = atoi(e) != 0;
     if (const char *e = getenv("UMX_GEMM_PP"))
         env_gemm_pp = atoi(e);
+    if (const char *e = getenv("UMX_GEMM_PS"))
+        env_gemm_ps = atoi(e);
     if (const char *e = getenv("UMX_LSTM8_POLL_DELAY")) // tuning: x64 cycles between a wave's publication and its first poll (lstm_batch8.h)
         lstm8_poll_delay = atoi(e);
     if (const char *e = getenv("UMX_LSTM8_PAIRED"))
@@ -885,7 +887,9 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 1, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_kernel<MODE, 2, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2))); \
     UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_pp_kernel<MODE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 1))); \
-    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_pp_kernel<MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2)));
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_pp_kernel<MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes(4, 4, 2))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_ps_kernel<MODE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(1))); \
+    UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_planes_ps_kernel<MODE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ps_lds_bytes(2)));
         UMX_GP_ATTR(G_FC1)
         UMX_GP_ATTR(G_IH)
         UMX_GP_ATTR(G_FC2)

@@ -62,6 +62,7 @@ void umx_hip_ctx::launch_gemm(Lane &sl, hipStream_t st, int mode, int layer, con
             g.t[i].Bq = mode == G_FC1 ? b.fc1_bx : mode == G_IH ? b.ih_bx[layer] : mode == G_FC2 ? b.fc2_bx : b.fc3_bx;
         }
     const dim3 grid((unsigned)round_up((g.N / GEMM_BN) * (g.M / GEMM_BM), 8), 1, nact), block(256);
+    gemm_kernel_last[mode] = "gemm_bf16x3_kernel";
 #define UMX_LAUNCH(KERNEL, LDS) hipLaunchKernelGGL((KERNEL), grid, block, LDS, st, g)
     switch (mode)
         {
@@ -213,8 +214,15 @@ void umx_hip_ctx::launch_gemm_planes(Lane &ln, int nl, hipStream_t st, int mode,
     // kernel, A/B on one box (round 3): fc1 5.70-5.98 -> 5.38-5.52, W_ih 5.69-6.14 -> 5.29-5.67, fc2 4.77 -> 4.62-4.66, fc3 9.21 -> 8.98-9.15.
     const int gemm_pp = env_gemm_pp; // UMX_GEMM_PP, read when the context was created
     const bool pp = big && (gemm_pp < 0 || ((gemm_pp >> mode) & 1));
+    // ... as a persistent kernel (gemm_planes_ps.h: one workgroup per CU walks the tiles of all targets, a tile's epilogue inside the
+    // next tile's first trip; same bits): launches with more tiles than CUs, UMX_GEMM_PS = bit per GemmMode (0: never)
+    const int ps_wgs = n_cus / 8 * 8;
+    const bool ps = pp && (env_gemm_ps < 0 || ((env_gemm_ps >> mode) & 1)) && g.K / GP_BK >= 6 && ps_wgs >= 8 && blocks_big > ps_wgs && g.Tp_lane >= 256;
+    gemm_kernel_last[mode] = ps ? "gemm_planes_ps_kernel" : pp ? "gemm_planes_pp_kernel" : "gemm_planes_kernel";
 #define UMX_GP(MODE)                                                                                                 \
-    if (pp && nbp == 1) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 1>), grid, dim3(512), lds, st, g);           \
+    if (ps && nbp == 1) hipLaunchKernelGGL((gemm_planes_ps_kernel<MODE, 1>), dim3(ps_wgs), dim3(512), ps_lds_bytes(1), st, g, nact); \
+    else if (ps) hipLaunchKernelGGL((gemm_planes_ps_kernel<MODE, 2>), dim3(ps_wgs), dim3(512), ps_lds_bytes(2), st, g, nact); \
+    else if (pp && nbp == 1) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 1>), grid, dim3(512), lds, st, g);           \
     else if (pp) hipLaunchKernelGGL((gemm_planes_pp_kernel<MODE, 2>), grid, dim3(512), lds, st, g);                  \
     else if (big && nbp == 1) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 1, 4, 4>), grid, block, lds, st, g);      \
     else if (big) hipLaunchKernelGGL((gemm_planes_kernel<MODE, 2, 4, 4>), grid, block, lds, st, g);                  \
@@ -271,6 +279,8 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
                              int nact)
 {
     stage_range(ST_STFT);
+    for (int i = 0; i < ST_COUNT; ++i) // (a stage's kernel-only event counts for the call that recorded it: umx_hip_stage_kernel_times_slot)
+        sl.evk_set[i] = false;
     UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_STFT], st));
     {
         StftIn in;

@@ -55,6 +55,16 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
         set_error("track: a phased segment is open (umx_hip_segment_end first)");
         return UMX_ERR_ARG;
     }
+    // Reset mode (UMX_FLAG_RESET_SEGMENTS, SURVEY 8(e)'s mode table): every segment starts from a ZERO lstm_data instead of the one
+    // the previous segment left behind (umx.cpp:167-171 makes it once per track, :226-227 hands it to every call) -- a declared
+    // deviation, opt-in.  The segments of a track are then independent, and up to B of them ride as the track lanes of ONE call.
+    const bool reset_lanes = (flags & UMX_FLAG_RESET_SEGMENTS) != 0;
+    flags &= ~(unsigned)UMX_FLAG_RESET_SEGMENTS;
+    if (reset_lanes && (nt != 1 || !lstm_batched || B < 2))
+    {
+        set_error("track: UMX_FLAG_RESET_SEGMENTS takes ONE track on a context made by umx_hip_create_tracks with at least 2 lanes");
+        return UMX_ERR_ARG;
+    }
     UMX_HIP_CHECK(hipSetDevice(device));
     if (int rc = sync_all())
         return rc;
@@ -74,12 +84,15 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
         L2[ln] = (int)l2;
         L2max = std::max(L2max, L2[ln]);
     }
-    if (trk.size() < (size_t)nt)
-        trk.resize(nt);
-    for (int ln = 0; ln < nt; ++ln)
+    const int stride = (int)((1 - 0.25f) * N); // umx.cpp:181, inference.hpp:15
+    // lanes whose per-segment stem buffers are needed: one per track, or (reset mode) one per segment of a call
+    const int seg_lanes = reset_lanes ? (int)std::min<long long>(B, ((long long)L2max + stride - 1) / stride) : nt;
+    if (trk.size() < (size_t)seg_lanes)
+        trk.resize(seg_lanes);
+    for (int ln = 0; ln < seg_lanes; ++ln)
     {
         TrackBufs &tb_ = trk[ln];
-        if ((size_t)L2[ln] > tb_.cap) // grow-only track buffers
+        if (ln < nt && (size_t)L2[ln] > tb_.cap) // grow-only track buffers
         {
             const size_t cap = (size_t)L2[ln] + (size_t)L2[ln] / 8;
             for (float **p : {&tb_.in, &tb_.out[0], &tb_.out[1], &tb_.out[2], &tb_.out[3], &tb_.sumw})
@@ -109,9 +122,9 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
         for (int s = 0; s < nslots; ++s)
             UMX_HIP_CHECK(hipEventCreateWithFlags(&trk_acc_ev[s], hipEventDisableTiming));
     // umx.cpp:167-171: a fresh, zeroed lstm_data per track; umx.cpp:186-195: zeroed accumulators (and F4)
-    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats() * nt));
+    UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats() * (reset_lanes ? B : nt)));
     clear_used();
-    for (int ln = 0; ln < nt; ++ln)
+    for (int ln = 0; ln < nt; ++ln) // (reset mode: nt = 1)
     {
         TrackBufs &tb_ = trk[ln];
         UMX_HIP_CHECK(hipMemset(tb_.in, 0, sizeof(float) * 2 * (size_t)L2[ln]));
@@ -122,7 +135,6 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
     }
     UMX_HIP_CHECK(hipDeviceSynchronize());
 
-    const int stride = (int)((1 - 0.25f) * N); // umx.cpp:181, inference.hpp:15
     const float total_reps = std::ceil((float)L2max / (float)stride); // umx.cpp:208 (of the longest track)
     float done = 0.f;
     // A sample is final once the segment that starts at or before it and the one before that have been blended
@@ -139,22 +151,38 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
             (void)hipEventDestroy(r.ready);
     };
     int last_slot = -1, iseg = 0;
-    for (long long off = 0; off < L2max; off += stride, ++iseg)
+    const int per_call = reset_lanes ? seg_lanes : 1; // segments of a track per call
+    for (long long off = 0; off < L2max; off += (long long)stride * per_call, ++iseg)
     {
-        const int offset = (int)off;
         const int si = next_slot();
         const float *ain[LSTMB_MAX_TRACKS] = {};
-        int nn[LSTMB_MAX_TRACKS] = {};
+        int nn[LSTMB_MAX_TRACKS] = {}, seg_off[LSTMB_MAX_TRACKS] = {};
         float *outs[4 * LSTMB_MAX_TRACKS] = {};
-        for (int ln = 0; ln < nt; ++ln)
-            if (offset < L2[ln]) // this track still has a segment here (umx.cpp:214-217)
+        const int nl = reset_lanes ? per_call : nt; // lanes of this call: lane = track (its segment at `off`), or lane k = segment k of the call
+        for (int ln = 0; ln < nl; ++ln)
+        {
+            const int ti = reset_lanes ? 0 : ln;
+            const long long so = reset_lanes ? off + (long long)ln * stride : off;
+            if (so < L2[ti]) // this track still has a segment here (umx.cpp:214-217)
             {
-                ain[ln] = trk[ln].in + 2 * (size_t)offset;
-                nn[ln] = std::min(N, L2[ln] - offset);
+                seg_off[ln] = (int)so;
+                ain[ln] = trk[ti].in + 2 * (size_t)so;
+                nn[ln] = std::min(N, L2[ti] - (int)so);
                 for (int t = 0; t < 4; ++t)
                     outs[4 * ln + t] = trk[ln].seg[si][t];
             }
-        const int rc = infer_batch(nt, ain, nn, outs, flags);
+        }
+        if (reset_lanes && iseg > 0) // every segment from a zero state: the previous call has left its own behind
+        {
+            if (int rc = sync_all())
+            {
+                cleanup();
+                return rc;
+            }
+            UMX_HIP_CHECK(hipMemset(state, 0, sizeof(float) * state_floats() * B));
+            UMX_HIP_CHECK(hipDeviceSynchronize());
+        }
+        const int rc = infer_batch(nl, ain, nn, outs, flags);
         if (rc)
         {
             cleanup();
@@ -163,22 +191,23 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
         hipStream_t st = slot[si].stream;
         if (last_slot >= 0) // accumulate in segment order (two segments overlap by a quarter)
             (void)hipStreamWaitEvent(st, trk_acc_ev[last_slot], 0);
-        for (int ln = 0; ln < nt; ++ln)
+        for (int ln = 0; ln < nl; ++ln)
         {
             if (!ain[ln])
                 continue;
+            const int ti = reset_lanes ? 0 : ln, offset = seg_off[ln];
             Stems4 tk, seg;
             for (int t = 0; t < 4; ++t)
             {
-                tk.p[t] = reinterpret_cast<float2 *>(trk[ln].out[t]);
+                tk.p[t] = reinterpret_cast<float2 *>(trk[ti].out[t]);
                 seg.p[t] = reinterpret_cast<float2 *>(trk[ln].seg[si][t]);
             }
-            hipLaunchKernelGGL(track_accumulate_kernel, dim3((nn[ln] + 255) / 256, 4), dim3(256), 0, st, tk, trk[ln].sumw, seg, offset, nn[ln], N);
+            hipLaunchKernelGGL(track_accumulate_kernel, dim3((nn[ln] + 255) / 256, 4), dim3(256), 0, st, tk, trk[ti].sumw, seg, offset, nn[ln], N);
             Region rg;
-            rg.lane = ln;
+            rg.lane = ti;
             rg.start = offset;
-            rg.count = (int)std::min<long long>(off + stride, L2[ln]) - offset;
-            hipLaunchKernelGGL(track_normalise_kernel, dim3((rg.count + 255) / 256, 4), dim3(256), 0, st, tk, trk[ln].sumw, rg.start, rg.count);
+            rg.count = (int)std::min<long long>((long long)offset + stride, L2[ti]) - offset;
+            hipLaunchKernelGGL(track_normalise_kernel, dim3((rg.count + 255) / 256, 4), dim3(256), 0, st, tk, trk[ti].sumw, rg.start, rg.count);
             if (hipEventCreateWithFlags(&rg.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(rg.ready, st) != hipSuccess)
             {
                 cleanup();

@@ -157,6 +157,12 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
 #ifndef PP_EXPERIMENT
 #define PP_EXPERIMENT 0
 #endif
+#ifndef PP_PROFILE
+#define PP_PROFILE 0 // 1 (timing build): one workgroup of the launch's second round prints where the cycles of its tile go
+#endif
+    [[maybe_unused]] long long pq[6] = {0, 0, 0, 0, 0, 0};
+    if (PP_PROFILE)
+        pq[0] = clock64();
     const int nk = K / GP_BK;
     if (grp == 0 || BOTH)
     {
@@ -170,6 +176,8 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
             PP_WAIT_VM(0);
     }
     PP_BARRIER() // tile 0 is there
+    if (PP_PROFILE)
+        pq[1] = clock64();
     if (grp == 1)
         PP_BARRIER() // group 1 runs one phase behind
     int cur = 0;
@@ -214,6 +222,8 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
     }
     if (grp == 0)
         PP_BARRIER() // group 1's last C phase
+    if (PP_PROFILE)
+        pq[2] = clock64();
 #undef PP_DMA
 #undef PP_LD
 #undef PP_LOAD
@@ -254,6 +264,8 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
                 asm volatile("" ::: "memory");
             }
     }
+    if (PP_PROFILE)
+        pq[3] = clock64();
     GemmTarget et;
     et.C = tg.C;
     et.e0 = tg.e0; et.e1 = tg.e1; et.e2 = tg.e2; et.e3 = tg.e3;
@@ -281,6 +293,15 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
     for (int half = 0; half < MI / 2; ++half)
         gemm_epilogue<MODE>(et, ea, m0 + wm * 32 * MI + half * 64, n0, 0, wn, lr, lh, acc[2 * half][0], acc[2 * half][1], acc[2 * half + 1][0],
                             acc[2 * half + 1][1]);
+    if (PP_PROFILE)
+    {
+        pq[4] = clock64();
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the stores are acknowledged
+        pq[5] = clock64();
+        if ((blockIdx.x == 264 || blockIdx.x == 2000) && blockIdx.z == 1 && (tid == 0 || tid == 64 * 4))
+            printf("# pp<%d,%d> wg %d wave %d trips %d: cycles  first-tile-wait %lld  main-loop %lld (%lld per trip)  fix-up %lld  epilogue-issue %lld  store-drain %lld  total %lld\n",
+                   MODE, NBP, (int)blockIdx.x, wave, nk, pq[1] - pq[0], pq[2] - pq[1], (pq[2] - pq[1]) / nk, pq[3] - pq[2], pq[4] - pq[3], pq[5] - pq[4], pq[5] - pq[0]);
+    }
 }
 
 } // namespace umx

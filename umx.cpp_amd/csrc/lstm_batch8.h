@@ -40,7 +40,13 @@ constexpr int LSTM8_OCTETS = 4;  // octets of a launch: 32 lanes
 __host__ __device__ inline size_t lstm8_granule_bytes(int Hl) { return (size_t)2 * 8 * (Hl / 2) * LSTM8_TRACKS * 16; }
 // LDS: h in fragment order [2 steps][Hl / 32 k-steps][4 k-groups][16 n] x 16 B, the eight k-range sums of h' [2][8 tracks][8 waves]
 __host__ __device__ inline size_t lstm8_h_bytes(int Hl) { return (size_t)(Hl / 32) * 4 * 16 * 16; }
-__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float) + 2 * 8 * LSTM8_UNITS * 2); } // no: octets per workgroup; + the row's planes staged for their store
+// the row's planes staged for their store: [2 planes][8 tracks] rows of 64 units at a pitch of 72 ushorts = 36 banks: the eight tracks of a
+// gate wave land on eight different bank quads (at 64 they shared one: 8-way conflicts, 224 of 240 conflict cycles per step and workgroup
+// in profiles/r05_v4_pmc_sq_counters.txt), and the 16-byte reads of the storing waves stay aligned (144 = 9 x 16)
+#ifndef LSTM8_STG_PITCH
+#define LSTM8_STG_PITCH 72
+#endif
+__host__ __device__ inline size_t lstm8_lds_bytes(int Hl, int no = 1) { return (size_t)no * (2 * lstm8_h_bytes(Hl) + 2 * 8 * 8 * sizeof(float) + 2 * 8 * LSTM8_STG_PITCH * 2); } // no: octets per workgroup
 
 // NO = octets a workgroup serves IN TURN (2: launches of 33 .. 64 lanes -- octet o and octet o + 4 with the same weight fragments).
 // A step of one octet is a dependent chain  publication -> L2 -> polls (a round of loads ~1,100 cycles + ~700 until the last wave's
@@ -81,7 +87,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
 
     unsigned char *const hl = smem;                                                        // [NO][2][NKS][4][16] x 16 B
     float *const hsp = reinterpret_cast<float *>(smem + (size_t)NO * 2 * HB);              // [NO][2][8 tracks][8 waves]
-    unsigned short *const stg = reinterpret_cast<unsigned short *>(smem + (size_t)NO * (2 * HB + 2 * 8 * 8 * sizeof(float))); // [NO][2 planes][8 tracks][64 units]
+    unsigned short *const stg = reinterpret_cast<unsigned short *>(smem + (size_t)NO * (2 * HB + 2 * 8 * 8 * sizeof(float))); // [NO][2 planes][8 tracks][LSTM8_STG_PITCH]
 
     // ---- W_hh fragments of the wave's two M tiles: lane (i = l & 15, q) holds gate column 16 mt + i (unit 4 mt + i / 4, gate i % 4), k = 32 ks + 8 q + j
     f16x8 Wf[2][NKS];
@@ -316,7 +322,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                 const int strk = l >> 3, sgrp = l & 7;
                 if ((mask8s[o] >> strk) & 1u)
                 {
-                    const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((o * 2 + w) * 8 + strk) * LSTM8_UNITS + sgrp * 8);
+                    const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((o * 2 + w) * 8 + strk) * LSTM8_STG_PITCH + sgrp * 8);
                     unsigned short *dst = a.planes[target] + (size_t)w * plane_elems + ((size_t)(lane0[o] + strk) * a.Tp + (size_t)(dir == 0 ? step - 1 : T - step)) * ldpl +
                                           a.col0 + dir * HL + shard * LSTM8_UNITS + sgrp * 8;
                     *reinterpret_cast<uint4 *>(dst) = val;
@@ -415,11 +421,22 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                     hlast[o] = h;
                     plast[o] = mine12;
                 }
-                if (LSTM8_STAGE_PLANES && have_planes)
+#ifndef LSTM8_STG_B32
+#define LSTM8_STG_B32 1
+#endif
+                if (LSTM8_STAGE_PLANES && have_planes && !LSTM8_STG_B32)
                 {
-                    unsigned short *sg = stg + (o * 2 * 8 + tr) * LSTM8_UNITS + w * 8 + tile * 4 + q;
+                    unsigned short *sg = stg + (o * 2 * 8 + tr) * LSTM8_STG_PITCH + w * 8 + tile * 4 + q;
                     sg[0] = (unsigned short)b1;
-                    sg[8 * LSTM8_UNITS] = (unsigned short)b2;
+                    sg[8 * LSTM8_STG_PITCH] = (unsigned short)b2;
+                }
+                if (LSTM8_STAGE_PLANES && have_planes && LSTM8_STG_B32 && (q & 1) == 0)
+                {
+                    // the even unit of a pair stages both (it holds the odd unit's planes for the granule): one dword per plane, the 32
+                    // writing lanes of a wave on 32 different banks
+                    unsigned *sg = reinterpret_cast<unsigned *>(stg + (o * 2 * 8 + tr) * LSTM8_STG_PITCH + w * 8 + tile * 4 + q);
+                    sg[0] = b1 | (other12 << 16);
+                    sg[8 * LSTM8_STG_PITCH / 2] = b2 | (other12 & 0xffff0000u);
                 }
                 // the even unit of a pair publishes it (this unit, the next), tagged step + 1
                 granule_store16<FAST>(gran_rs[o], (lane_on[o] && (q & 1) == 0) ? (step & 1) * gslot + pub_off : LSTM8_OOR,
