@@ -563,10 +563,7 @@ def main():
                        "audio_seconds_per_step": B * seg_sec,
                        "lstm_kernel": ({"lstm_batch8_kernel": "batched, matrix cores, workgroups of 8 lanes x 64 hidden units" +
                                                               (", two octets per workgroup in turn" if B > 32 else "") + " (lstm_batch8_kernel)",
-                                        "lstm_batcht_kernel": "batched, matrix cores, two side-by-side pairs of 16-lane groups in turn (lstm_batcht_kernel)",
-                                        "lstm_batch2_kernel": "batched, matrix cores, groups of 16 lanes in turn (lstm_batch2_kernel)",
-                                        "lstm_batchs_kernel": "batched, matrix cores, two groups of 16 lanes side by side (lstm_batchs_kernel)",
-                                        "lstm_batch_kernel": "batched, matrix cores (lstm_batch_kernel)"}.get(lstm_kernel, lstm_kernel)
+                                        "lstm_batch_kernel": "batched, matrix cores, groups of 16 lanes one launch after the other (lstm_batch_kernel)"}.get(lstm_kernel, lstm_kernel)
                                        if batched else "single-track, VALU (lstm_persistent_kernel)"),
                        "lstm": {0: "stepwise", 1: "persistent (sc1 hand-off)", 2: "persistent (intra-XCD hand-off)"}.get(lstm_mode, "?"),
                        "gemm": (flavour + (" (fp16 matrix cores, f32 accumulate: activations split once into 2 fp16 planes of the power-of-two "

@@ -126,13 +126,13 @@ int umx_hip_create_ex(umx_hip_ctx **out, int device, int hidden_size, int segmen
  * UMX_LSTM=batched, on a 1-track context) selects the batched kernel for every call, so a track's result never
  * depends on how many lanes a call uses or which lane it sits in (bitwise; tests/test_gpu_batch.py).  Against the
  * single-track kernel the results agree to fp32 rounding (different summation order), not bitwise.
- * Hidden 1024 with the u8-resident W_hh of a quantised model (any number of lanes): csrc/lstm_batch8.h -- a workgroup serves an octet
- * of 8 lanes x 64 hidden units (N of the matrix instruction = 8 lanes x the 2 planes of h), up to 32 lanes per launch with one octet per
- * workgroup, 33 .. 64 with two octets per workgroup IN TURN (one octet's hand-off travels under the other's matrix and gate phases).
- * Other hidden sizes / fp32-resident W_hh: csrc/lstm_batch.h (<= 16 lanes; 17 .. 32 two groups of 16 side by side; 33 .. 64 two such
- * pairs in turn) and csrc/lstm_batch2.h (groups in turn, <= 48 lanes); more than 16 lanes always need the u8-resident W_hh. */
+ * Hidden 1024 (UMX-L) and 512 (umxhq) with the u8-resident W_hh of a quantised model, any number of lanes: csrc/lstm_batch8.h -- a
+ * workgroup serves an octet of 8 lanes x 64 hidden units (N of the matrix instruction = 8 lanes x the 2 planes of h); hidden 1024: 32
+ * lanes per launch with one octet per workgroup, 33 .. 64 with two octets per workgroup IN TURN (one octet's hand-off travels under
+ * the other's matrix and gate phases); hidden 512: its 64 lanes side by side.  Other hidden sizes / fp32-resident W_hh:
+ * lstm_batch_kernel of csrc/lstm_batch.h, a group of 16 lanes per launch, the groups of a larger context one launch after the other. */
 #define UMX_CREATE_LSTM_BATCHED 0x10u
-#define UMX_MAX_TRACKS 64 /* more than 16 need a quantised model with its u8 W_hh resident */
+#define UMX_MAX_TRACKS 64
 int umx_hip_create_tracks(umx_hip_ctx **out, int device, int hidden_size, int segment_samples,
                           const umx_tensor_view *tensors, int n_tensors, unsigned create_flags, int n_tracks);
 int umx_hip_n_tracks(const umx_hip_ctx *ctx);
@@ -322,8 +322,7 @@ int umx_hip_stage_kernel_times_slot(umx_hip_ctx *ctx, int slot_index, float *ms,
  * 0 if the per-timestep driver was used (flag, unsupported hidden size, or grid not co-resident). */
 int umx_hip_lstm_was_persistent(const umx_hip_ctx *ctx);
 /* The recurrence kernel the last LSTM layer launch used: "lstm_persistent_kernel" / "lstm_step_kernel" (one track),
- * "lstm_batch8_kernel" (track-batched, hidden 1024), "lstm_batch_kernel" / "lstm_batchs_kernel" / "lstm_batcht_kernel" /
- * "lstm_batch2_kernel" (the forms of csrc/lstm_batch.h, lstm_batch2.h). */
+ * "lstm_batch8_kernel" (track-batched, hidden 1024 / 512, u8-resident W_hh), "lstm_batch_kernel" (every other track-batched context). */
 const char *umx_hip_lstm_kernel_name(const umx_hip_ctx *ctx);
 /* The GEMM kernel the last call launched for stage `mode` (0 fc1, 1 W_ih, 2 fc2, 3 fc3): "gemm_planes_ps_kernel" (persistent walk),
    "gemm_planes_pp_kernel", "gemm_planes_kernel", "gemm_bf16x3_kernel" or "none".  For bench.py's per-kernel figures: no reference analogue. */

@@ -199,12 +199,10 @@ def test_hot_kernels_keep_their_register_budgets(device_asm):
         assert vg <= 256 and sp == 0, (mode, nbp, vg, sp)
     vg, sp = find("gemm_planes_pp_kernelILi3ELi2E")
     assert vg <= 256 and sp <= 16, (vg, sp)
-    # batched recurrence, two groups: 12 waves per CU = at most 168
-    vg, sp = find("lstm_batch2_kernelILi512ELi2ELb0E")
-    assert vg <= 168 and sp == 0, (vg, sp)
-    # two groups of 16 lanes side by side, chains of 16 workgroups with two slices each (one workgroup per CU): nothing spilled
-    vg, sp = find("lstm_batchs_kernelILi512ELb0ELi2E")
-    assert vg <= 256 and sp == 0, (vg, sp)
+    # persistent plane GEMMs (round 6): the main loop without a spill in any form; the epilogue trip of fc3 may keep its handful
+    for mode, nbp in ((0, 1), (1, 1), (2, 2), (3, 2)):
+        vg, sp = find(f"gemm_planes_ps_kernelILi{mode}ELi{nbp}E")
+        assert vg <= 256 and sp <= 16, (mode, nbp, vg, sp)
     # octets of 8 lanes x column shards of 64 units (round 5; NO = octets per workgroup in turn): 128 registers of W_hh fragments per
     # wave; the PROLOGUE (256 byte loads per lane into those fragments) spills, the step loops (intra-XCD and sc1 protocol) must not
     for no in (1, 2):

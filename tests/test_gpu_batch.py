@@ -60,8 +60,8 @@ def test_track_bits_do_not_depend_on_lane_companions_or_batch_size(pkg, tmp_path
     other = [pkg.ggml.synth_audio(N, 950 + i) for i in range(64)]
     results = []
     for B, lane, flags in ((1, 0, 0), (4, 2, 0), (16, 13, 0), (4, 1, pkg.FLAG_LSTM_STEPWISE), (4, 3, pkg.FLAG_LSTM_FORCE_SAFE),
-                           (32, 5, 0), (32, 29, 0), (20, 17, pkg.FLAG_LSTM_STEPWISE), (24, 21, pkg.FLAG_LSTM_FORCE_SAFE),  # > 16: lstm_batch2.h
-                           (48, 44, 0), (40, 35, pkg.FLAG_LSTM_STEPWISE),  # 33 .. 64: lstm_batcht_kernel (two side-by-side pairs in turn)
+                           (32, 5, 0), (32, 29, 0), (20, 17, pkg.FLAG_LSTM_STEPWISE), (24, 21, pkg.FLAG_LSTM_FORCE_SAFE),  # up to 32 lanes: one octet per workgroup
+                           (48, 44, 0), (40, 35, pkg.FLAG_LSTM_STEPWISE),  # 33 .. 64: two octets per workgroup in turn
                            (64, 50, 0), (64, 3, 0), (56, 33, pkg.FLAG_LSTM_STEPWISE), (40, 19, pkg.FLAG_LSTM_FORCE_SAFE)):
         eng = pkg.Engine.from_file(path, N, tracks=B, lstm_batched=True)
         outs = []
@@ -176,39 +176,72 @@ def test_persistent_gemm_gives_the_bits_of_the_ping_pong_kernel(pkg, tmp_path, m
             assert (res[ps][1][b] == res["15"][1][b]).all(), (ps, b)
 
 
-def test_groups_side_by_side_give_the_bits_of_the_groups_in_turn(pkg, tmp_path, monkeypatch):
-    """17 .. 32 lanes, hidden 1024: csrc/lstm_batch.h's lstm_batchs_kernel (round 4: the two groups of 16 lanes side by side on the chip,
-    every chain 16 workgroups of two slices -- half the hand-off bytes per step) against csrc/lstm_batch2.h (the groups in turn through
-    256 twelve-wave workgroups; UMX_LSTM_GROUPED=0): per (unit, lane) the same matrix instructions in the same order and the same
-    summation tree, so stems and carried state agree bit for bit -- 20 and 32 lanes (a group with four lanes, two full groups), ragged
-    lengths, two segments, and the per-step driver of the new form."""
-    H, N = 1024, 40 * 1024
-    path = str(tmp_path / "m.bin")
-    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=53), H, compress=False)
-    # (hidden 1024 runs csrc/lstm_batch8.h by default since the end of round 5 -- other sums, its own tests below; the kernels compared
-    # here remain for the other hidden sizes and behind this switch)
-    monkeypatch.setenv("UMX_LSTM8_MIN_LANES", "99")
-    for B in (20, 32, 40, 64):  # 40, 64 (round 5): lstm_batcht_kernel, two such pairs in turn, against lstm_batch2.h's three groups in turn
-        waves = [[pkg.ggml.synth_audio(N - 97 * b, 2300 + 10 * b + s) for b in range(B)] for s in range(2)]
-        res = {}
-        for mode in (("0", None, "stepwise") if B <= 48 else ("stepwise", None)):  # (more than 48 lanes exist only in the new form)
-            if mode == "0":
-                monkeypatch.setenv("UMX_LSTM_GROUPED", "0")
-            else:
-                monkeypatch.delenv("UMX_LSTM_GROUPED", raising=False)
-            eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
-            flags = pkg.FLAG_LSTM_STEPWISE if mode == "stepwise" else 0
-            outs = [eng.infer_batch(w, flags) for w in waves]
-            res[mode] = (outs, [eng.track_stream_get(b) for b in range(B)])
-            eng.close()
-        base = "0" if B <= 48 else "stepwise"
-        for mode in (None, "stepwise"):
+def test_groups_of_16_lanes_one_launch_after_the_other_give_a_lane_its_bits(pkg, tmp_path, monkeypatch):
+    """Contexts that csrc/lstm_batch8.h does not take -- hidden 256 / 128, fp32-resident W_hh, or UMX_LSTM8_MIN_LANES=99 -- run
+    lstm_batch_kernel, one group of 16 lanes per launch, the groups of a larger context one after the other (round 6: the side-by-side,
+    in-turn and twelve-wave forms of rounds 2-5 are gone).  A lane's stems and carried state must be the bits it has in a context of
+    one group, whichever group it sits in: hidden 1024 on the older kernel (20 and 40 lanes, persistent and per-step), hidden 256
+    (24 lanes), and fp32-resident weights (20 lanes)."""
+    N = 24 * 1024
+    for H, quantised, env, cases in ((1024, True, "99", ((20, 17, 0), (40, 35, 0), (40, 9, pkg.FLAG_LSTM_STEPWISE))),
+                                     (256, True, None, ((24, 21, 0),)),
+                                     (512, False, None, ((20, 18, 0),))):
+        if env is None:
+            monkeypatch.delenv("UMX_LSTM8_MIN_LANES", raising=False)
+        else:
+            monkeypatch.setenv("UMX_LSTM8_MIN_LANES", env)
+        path = str(tmp_path / f"m{H}{int(quantised)}.bin")
+        pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=71), H, compress=False)
+        track = [pkg.ggml.synth_audio(N, 2900 + s) for s in range(2)]
+        other = [pkg.ggml.synth_audio(N, 2950 + i) for i in range(40)]
+        results = []
+        for B, lane, flags in ((3, 1, 0),) + cases:
+            eng = pkg.Engine.from_file(path, N, tracks=B, quantised=quantised)
+            outs = []
             for s in range(2):
-                for b in range(B):
-                    for t in range(4):
-                        assert (res[mode][0][s][b][t] == res[base][0][s][b][t]).all(), (B, mode, s, b, t)
-            for b in range(B):
-                assert (res[mode][1][b] == res[base][1][b]).all(), (B, mode, b)
+                batch = [other[(i + s) % 40] for i in range(B)]
+                batch[lane] = track[s]
+                outs.append(eng.infer_batch(batch, flags)[lane])
+            assert eng.lstm_kernel_name() == "lstm_batch_kernel", (H, B)
+            results.append((outs, eng.track_stream_get(lane), B, lane, flags))
+            eng.close()
+        for outs, state, B, lane, flags in results[1:]:
+            assert (state == results[0][1]).all(), (H, B, lane, flags)
+            for s in range(2):
+                for t in range(4):
+                    assert (outs[s][t] == results[0][0][s][t]).all(), (H, B, lane, flags, s, t)
+
+
+def test_umxhq_width_runs_the_octet_recurrence(pkg, po, tmp_path):
+    """hidden 512 (umxhq; src/model.cpp:109-114,136-137 read the width from the file): csrc/lstm_batch8.h with LSTM hidden 256 -- four
+    column shards per chain, eight octets side by side, 64 lanes in ONE launch -- against the oracle per lane, and the bits of the same
+    track in a small context and through the per-step driver."""
+    H, N, B = 512, 24 * 1024, 40
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=73), H, compress=False)
+    om = po.Model.load(path)
+    waves = [[pkg.ggml.synth_audio(N - 131 * b, 3500 + 10 * b + s) for b in range(B)] for s in range(2)]
+    eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
+    got = [eng.infer_batch(w) for w in waves]
+    assert eng.lstm_kernel_name() == "lstm_batch8_kernel" and eng.lstm_was_persistent()
+    states = [eng.track_stream_get(b) for b in range(B)]
+    eng.close()
+    for b in (0, 9, 39):
+        ref, ref_state = _oracle_track(po, om, H, [waves[0][b], waves[1][b]], N)
+        for s in range(2):
+            for t in range(4):
+                assert float(np.abs(got[s][b][t] - ref[s][t]).max()) < TOL_WAVE, (b, s, t)
+        assert rel_l2(states[b], ref_state) < TOL_STAGE, b
+    for B2, flags in ((3, 0), (12, pkg.FLAG_LSTM_STEPWISE)):
+        small = pkg.Engine.from_file(path, N, tracks=B2, quantised=True)
+        outs = [small.infer_batch([waves[s][9], waves[s][0], waves[s][39]] + [waves[s][1]] * (B2 - 3), flags) for s in range(2)]
+        assert small.lstm_kernel_name() == "lstm_batch8_kernel"
+        for k, b in enumerate((9, 0, 39)):
+            assert (small.track_stream_get(k) == states[b]).all(), (B2, b)
+            for s in range(2):
+                for t in range(4):
+                    assert (outs[s][k][t] == got[s][b][t]).all(), (B2, b, s, t)
+        small.close()
 
 
 def test_two_octets_in_turn_give_the_bits_of_two_launches(pkg, tmp_path, monkeypatch):

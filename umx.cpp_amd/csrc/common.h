@@ -66,6 +66,42 @@ __device__ __forceinline__ float2 unit_phasor(float2 x)
     const float ra = __builtin_amdgcn_rcpf(a);
     return a > 1e-18f ? make_float2(div_by(x.x, a, ra), div_by(x.y, a, ra)) : make_float2(1.f, 0.f);
 }
+// Streams: data a kernel reads or writes once and nobody touches again before the kernel has ended (the spectrogram, W_ih x + b_ih, the
+// A planes the recurrence leaves for the next GEMM).  Non-temporal accesses keep them from pushing what IS re-used -- weight tiles,
+// hand-off granules -- out of the L2s (profiles/r06_ps_store_policy.txt, r06_nt_streams_ab.txt).  -DUMX_NT_STREAMS=0: A/B builds.
+#ifndef UMX_NT_STREAMS
+#define UMX_NT_STREAMS 1
+#endif
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 stream_load4(const float *p)
+{
+    if (!UMX_NT_STREAMS)
+        return *reinterpret_cast<const float4 *>(p);
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stream_store2(float2 *p, float2 v)
+{
+    if (!UMX_NT_STREAMS)
+        *p = v;
+    else
+    {
+        const nt_f2 t = {v.x, v.y};
+        __builtin_nontemporal_store(t, reinterpret_cast<nt_f2 *>(p));
+    }
+}
+__device__ __forceinline__ void stream_store4u(uint4 *p, uint4 v)
+{
+    if (!UMX_NT_STREAMS)
+        *p = v;
+    else
+    {
+        const nt_u4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<nt_u4 *>(p));
+    }
+}
 // element (channel c, frame f, bin b) of a mask plane [2][T][MAGP]
 __device__ __forceinline__ size_t mask_index(int c, int T, int f, int b) { return ((size_t)c * T + f) * MAGP + b; }
 

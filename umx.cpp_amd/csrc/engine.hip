@@ -30,7 +30,6 @@
 #include "gemm_planes_ps.h"
 #include "lstm_kernels.h"
 #include "lstm_batch.h"
-#include "lstm_batch2.h"
 #include "lstm_batch8.h"
 #include "track_kernels.h"
 #include "stft_kernels.h"
@@ -321,54 +320,20 @@ template <int HL> static const void *lstm_batch_fn_hl(bool wq, bool precise)
               : (precise ? reinterpret_cast<const void *>(lstm_batch_kernel<HL, false, true>)
                          : reinterpret_cast<const void *>(lstm_batch_kernel<HL, false, false>));
 }
-template <int G> static const void *lstm_batch2_fn_g(int Hl, bool precise)
-{
-    switch (Hl)
-    {
-    case 64: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<64, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<64, G, false>);
-    case 128: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<128, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<128, G, false>);
-    case 256: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<256, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<256, G, false>);
-    case 512: return precise ? reinterpret_cast<const void *>(lstm_batch2_kernel<512, G, true>) : reinterpret_cast<const void *>(lstm_batch2_kernel<512, G, false>);
-    default: return nullptr;
-    }
-}
-// two or three groups of 16 lanes (lstm_batch2.h): u8-resident W_hh only
-static const void *lstm_batch2_fn(int Hl, int groups, bool precise) { return groups == 3 ? lstm_batch2_fn_g<3>(Hl, precise) : lstm_batch2_fn_g<2>(Hl, precise); }
 #ifndef UMX_FUSE_LSTM_PLANES
 #define UMX_FUSE_LSTM_PLANES 1
 #endif
-static int lstmb2_bulk(int groups) { return groups == 3 ? 2 : 4; } // ring rows per fetch: what fits the LDS beside the partial sums
-// two groups of 16 lanes side by side on the chip, chains of 16 workgroups with two slices each (lstm_batchs_kernel): hidden 512 / 1024,
-// u8-resident W_hh
-static const void *lstm_batchs_fn(int Hl, int groups, bool precise)
+// octets of 8 lanes x column shards of 64 units (lstm_batch8.h): LSTM hidden 512 (UMX-L) and 256 (umxhq), u8-resident W_hh
+template <int HL> static const void *lstm_batch8_fn_hl(bool precise, int no)
 {
-    if (groups != 2)
-        return nullptr;
-    switch (Hl)
-    {
-    case 256: return precise ? reinterpret_cast<const void *>(lstm_batchs_kernel<256, true, 2>) : reinterpret_cast<const void *>(lstm_batchs_kernel<256, false, 2>);
-    case 512: return precise ? reinterpret_cast<const void *>(lstm_batchs_kernel<512, true, 2>) : reinterpret_cast<const void *>(lstm_batchs_kernel<512, false, 2>);
-    default: return nullptr;
-    }
-}
-static const void *lstm_batcht_fn(int Hl, bool precise) // 33 .. 64 lanes: two side-by-side pairs of groups in turn (lstm_batch.h)
-{
-    if (Hl == 512)
-        return precise ? reinterpret_cast<const void *>(lstm_batcht_kernel<512, true, 2>) : reinterpret_cast<const void *>(lstm_batcht_kernel<512, false, 2>);
-    if (Hl == 256)
-        return precise ? reinterpret_cast<const void *>(lstm_batcht_kernel<256, true, 2>) : reinterpret_cast<const void *>(lstm_batcht_kernel<256, false, 2>);
-    return nullptr;
-}
-// octets of 8 lanes x column shards of 64 units (lstm_batch8.h): hidden 512, u8-resident W_hh
-static const void *lstm_batch8_fn(int Hl, bool precise, int no = 1) // no = 2: two octets per workgroup in turn (33 .. 64 lanes in one launch)
-{
-    if (Hl != 512)
-        return nullptr;
     if (no == 2)
-        return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<512, true, 2>) : reinterpret_cast<const void *>(lstm_batch8_kernel<512, false, 2>);
-    return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<512, true, 1>) : reinterpret_cast<const void *>(lstm_batch8_kernel<512, false, 1>);
+        return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<HL, true, 2>) : reinterpret_cast<const void *>(lstm_batch8_kernel<HL, false, 2>);
+    return precise ? reinterpret_cast<const void *>(lstm_batch8_kernel<HL, true, 1>) : reinterpret_cast<const void *>(lstm_batch8_kernel<HL, false, 1>);
 }
-constexpr int kBatchsBulk = 1, kBatchsSpan = 2; // ring rows per fetch (LDS: 128 KB of partial sums + 2 rows x 16 lanes x 528 B), slices per workgroup
+static const void *lstm_batch8_fn(int Hl, bool precise, int no = 1) // no = 2: two octets per workgroup in turn (hidden 1024: 33 .. 64 lanes in one launch)
+{
+    return Hl == 512 ? lstm_batch8_fn_hl<512>(precise, no) : Hl == 256 ? lstm_batch8_fn_hl<256>(precise, no) : nullptr;
+}
 static const void *lstm_batch_fn(int Hl, bool wq, bool precise)
 {
     switch (Hl)
@@ -451,9 +416,8 @@ struct umx_hip_ctx
     bool no_recovery = false, recovering = false;
     int recover();
     int lstm_poll_delay = 0;         // 0 = the kernel's default (LSTM_POLL_DELAY)
-    bool env_lstm_grouped = true;    // UMX_LSTM_GROUPED (0: 17 .. 32 lanes as groups in turn) and UMX_GEMM_PP (bit mask of the GEMMs that
     int env_gemm_ps = -1;            // UMX_GEMM_PS: bit per GemmMode, which 256 x 256 launches take the persistent kernel (gemm_planes_ps.h); < 0: all
-    int env_gemm_pp = -1;            // take the ping-pong kernel; < 0: all) are read ONCE, when the context is created: a test makes a context per mode
+    int env_gemm_pp = -1;            // UMX_GEMM_PP: bit mask of the GEMMs that take the ping-pong kernel; < 0: all.  Both are read ONCE, when the context is created: a test makes a context per mode
     const char *gemm_kernel_last[4] = {"none", "none", "none", "none"}; // per GemmMode (umx_hip_gemm_kernel_name)
     const char *lstm_kernel_last = "none"; // the recurrence kernel of the last layer launch (umx_hip_lstm_kernel_name)
     int lstm_threads = LSTM_THREADS; // 512 (two workgroups per CU fit) or 576 (dedicated gate wave)
@@ -504,10 +468,8 @@ struct umx_hip_ctx
     int lstm8_poll_delay = 0;    // UMX_LSTM8_POLL_DELAY (read at create)
     bool env_lstm8_paired = true; // UMX_LSTM8_PAIRED=0 (read at create): 33 .. 64 lanes as two launches of 32 instead of two octets per workgroup in turn
     int env_lstm8_min = 1;       // UMX_LSTM8_MIN_LANES (read at create): contexts of at least this many lanes use it (99: none)
-    bool lstm_batcht_ok = false; // lstm_batcht_kernel (33 .. 64 lanes: two such pairs in turn) fits the chip
-    bool lstm_batchs_ok = false; // lstm_batchs_kernel (two groups of 16 lanes side by side, 16 workgroups per chain) fits the chip
     bool lstm_rowsums = false;       // the batched recurrence hands the consuming plane GEMM the row sums of its output (lstm_batch.h, LstmBArgs::rs_dir)
-    bool lstm_writes_planes = false; // ... and writes that GEMM's A planes itself (contexts of up to 32 lanes: lstm_batch_kernel / lstm_batchs_kernel)
+    bool lstm_writes_planes = false; // ... and writes that GEMM's A planes itself
     size_t state_floats() const { return (size_t)4 * 12 * Hl; }
     // phased form of one segment (exact multi-GPU carry): front | layer 0 | layer 1 | layer 2 | back
     // whole track on the device (split_inference / shift_inference, umx.cpp:99-295)

@@ -164,8 +164,6 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
     // Track-batched contexts fuse the Wiener filter with the inverse STFT (wiener_istft.h: one 1024-thread, 136 KB-LDS
     // workgroup per frame); the single-track context keeps the small kernels, which run beside the other slot's LSTM
     // grids (measured: fused 7.85 ms per segment in the pipeline, unfused 7.41).  UMX_WIENER = fused | stats4 | unfused.
-    if (const char *e = getenv("UMX_LSTM_GROUPED"))
-        env_lstm_grouped = atoi(e) != 0;
     if (const char *e = getenv("UMX_GEMM_PP"))
         env_gemm_pp = atoi(e);
     if (const char *e = getenv("UMX_GEMM_PS"))
@@ -780,86 +778,34 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
                     UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstmb_lds_bytes(B > 8 ? 16 : B > 4 ? 8 : B > 2 ? 4 : B > 1 ? 2 : 1, B > 8 ? 8 : 16)));
                     per_cu = std::min(per_cu, v);
                 }
-            if (B > LSTMB_GROUP_TRACKS) // more than 16 lanes: the two-group kernel (u8-resident W_hh only)
-            {
-                for (int l = 0; l < 3; ++l)
-                    if (!whh_q[l] || u8_dequant)
-                    {
-                        set_error("more than 16 track lanes need the u8-resident W_hh (quantised model, no UMX_CREATE_U8_DEQUANT / _DEQUANTISE_AT_LOAD)");
-                        return UMX_ERR_ARG;
-                    }
-                for (int groups = 2; groups <= 3; ++groups)
-                    for (int precise = 0; precise < 2; ++precise)
-                    {
-                        const void *fn = lstm_batch2_fn(Hl, groups, precise != 0);
-                        const size_t l2 = lstmb2_lds_bytes(groups, lstmb2_bulk(groups));
-                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
-                        int v = 0;
-                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTMB2_THREADS, l2));
-                        per_cu = std::min(per_cu, v);
-                    }
-                // ... or two groups side by side, each chain 16 workgroups of two slices: one workgroup per CU
-                lstm_batchs_ok = false;
-                if (lstm_batchs_fn(Hl, 2, false) && S % kBatchsSpan == 0)
-                {
-                    const size_t lg = lstmb_lds_bytes(LSTMB_GROUP_TRACKS, kBatchsBulk, kBatchsSpan);
-                    lstm_batchs_ok = true;
-                    for (int precise = 0; precise < 2; ++precise)
-                    {
-                        const void *fn = lstm_batchs_fn(Hl, 2, precise != 0);
-                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
-                        int v = 0;
-                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lg));
-                        lstm_batchs_ok = lstm_batchs_ok && v >= 1 && 2 * 8 * (S / kBatchsSpan) <= v * cus;
-                    }
-                }
-                // ... or, for 33 .. 64 lanes, two such pairs in turn through the same grid
-                lstm_batcht_ok = false;
-                if (B > 32 && lstm_batcht_fn(Hl, false) && S % kBatchsSpan == 0)
-                {
-                    const size_t lg = lstmb_lds_bytes(LSTMB_GROUP_TRACKS, kBatchsBulk, kBatchsSpan) + LSTMB_HSW_BYTES;
-                    lstm_batcht_ok = true;
-                    for (int precise = 0; precise < 2; ++precise)
-                    {
-                        const void *fn = lstm_batcht_fn(Hl, precise != 0);
-                        UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lg));
-                        int v = 0;
-                        UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lg));
-                        lstm_batcht_ok = lstm_batcht_ok && v >= 1 && 2 * 8 * (S / kBatchsSpan) <= v * cus;
-                    }
-                }
-                if (B > 48 && !(lstm_batcht_ok && env_lstm_grouped))
-                {
-                    set_error("more than 48 track lanes need lstm_batcht_kernel (LSTM hidden 256 or 512, the grid co-resident, no UMX_LSTM_GROUPED=0)");
-                    return UMX_ERR_ARG;
-                }
-            }
-            // octets of 8 lanes x column shards of 64 units (lstm_batch8.h): chosen by the CONTEXT's lane count, for every launch of the
-            // context -- its sums are not the bits of the kernels above, and a lane's result must not depend on who rides along
+            // octets of 8 lanes x column shards of 64 units (lstm_batch8.h): LSTM hidden 512 / 256 with the u8-resident W_hh, chosen per
+            // CONTEXT and used for every launch of it -- its sums are not the bits of lstm_batch_kernel, and a lane's result must not depend on
+            // who rides along.  Everything else (hidden 256 / 128, fp32-resident W_hh, UMX_LSTM8_MIN_LANES=99) runs lstm_batch_kernel, a group
+            // of 16 lanes per launch, the groups one after the other.
             lstm_batch8_ok = false;
-            if (env_lstm_grouped && B >= env_lstm8_min && B <= 2 * LSTM8_OCTETS * LSTM8_TRACKS && lstm_batch8_fn(Hl, false) && S == 32 && !u8_dequant && whh_q[0] && whh_q[1] && whh_q[2])
+            if (B >= env_lstm8_min && lstm_batch8_fn(Hl, false) && !u8_dequant && whh_q[0] && whh_q[1] && whh_q[2])
             {
                 lstm_batch8_ok = true;
+                int per_cu8 = 1 << 30;
                 for (int precise = 0; precise < 2; ++precise)
-                {
                     for (int no = 1; no <= 2; ++no)
                     {
                         const void *fn = lstm_batch8_fn(Hl, precise != 0, no);
                         UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lstm8_lds_bytes(Hl, no)));
                         int v = 0;
                         UMX_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, LSTM_THREADS, lstm8_lds_bytes(Hl, no)));
-                        lstm_batch8_ok = lstm_batch8_ok && v >= 1 && 8 * 32 <= v * cus;
+                        per_cu8 = std::min(per_cu8, v);
                     }
-                }
+                lstm_batch8_ok = per_cu8 >= 1 && 8 * 32 <= per_cu8 * cus;
+                if (lstm_batch8_ok) // the persistent launches of this context are lstm_batch8_kernel's: its occupancy decides
+                    per_cu = per_cu8;
             }
             lstm_batch_capacity = per_cu * cus;
             // the recurrence writes the plane GEMMs' A operands (layers 1, 2 and fc2's right half) and their row sums itself where
             // it runs on the u8-resident W_hh (its gate lanes hold h as two fp16 planes, its all-ones tile the row sums): no
             // split_planes launches for them (lstm_batch.h, LstmBArgs::planes).  -DUMX_FUSE_LSTM_PLANES=0: A/B builds
-            // More than 32 lanes (lstm_batch2.h, no register left): only the row sums; split_planes_kernel still writes the planes -- the
-            // same bits, so a track's result does not depend on the size of the context.
             lstm_rowsums = UMX_FUSE_LSTM_PLANES && gemm_planes && !u8_dequant && whh_q[0] && whh_q[1] && whh_q[2];
-            lstm_writes_planes = lstm_rowsums && (B <= 2 * LSTMB_GROUP_TRACKS || lstm_batch8_ok);
+            lstm_writes_planes = lstm_rowsums;
         }
     }
     // dynamic LDS > 64 KiB must be opted into

@@ -160,32 +160,23 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     for (int ln = 0; ln < LSTMB_MAX_TRACKS; ++ln)
         if ((lane_mask >> ln) & 1ull)
             top = ln + 1;
-    const int groups = (top + LSTMB_GROUP_TRACKS - 1) / LSTMB_GROUP_TRACKS; // > 1: lstm_batch2.h, groups of 16 lanes in turn
-    a.nbp = top > 8 ? 16 : top > 4 ? 8 : top > 2 ? 4 : top > 1 ? 2 : 1;
     const bool wq = whh_q[layer] != nullptr && !u8_dequant;
-    // 17 .. 32 lanes: the two groups side by side on the chip (lstm_batchs_kernel: half the hand-off bytes) where it fits, else -- and
-    // for 33 .. 48 lanes -- the groups in turn through one twelve-wave workgroup (lstm_batch2.h).  Same bits either way.
-    const bool octets = lstm_batch8_ok; // lstm_batch8.h: every launch of this context, whatever lanes take part
-    const bool grouped = !octets && groups == 2 && lstm_batchs_ok && env_lstm_grouped; // UMX_LSTM_GROUPED=0 (read at create): always the groups in turn
-    // 33 .. 64 lanes: two such side-by-side pairs IN TURN through the same 256 workgroups (lstm_batcht_kernel, round 5); else lstm_batch2.h
-    const bool turned = !octets && groups >= 3 && groups <= 4 && lstm_batcht_ok && env_lstm_grouped;
-    a.bulk = (grouped || turned) ? kBatchsBulk : groups > 1 ? lstmb2_bulk(groups) : a.nbp > 8 ? 8 : 16;
-    const int octs = octets && env_lstm8_paired && top > LSTM8_OCTETS * LSTM8_TRACKS ? 2 : 1; // octets per workgroup, in turn
-    const size_t lds = octets    ? lstm8_lds_bytes(Hl, octs)
-                       : turned  ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan) + LSTMB_HSW_BYTES // (the second turn's k-range sums of h')
-                       : grouped ? lstmb_lds_bytes(LSTMB_GROUP_TRACKS, a.bulk, kBatchsSpan)
-                       : groups > 1        ? lstmb2_lds_bytes(groups, a.bulk)
-                                           : lstmb_lds_bytes(a.nbp, a.bulk);
-    const void *fn = octets       ? lstm_batch8_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT, octs)
-                     : turned     ? lstm_batcht_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT)
-                     : grouped    ? lstm_batchs_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
-                     : groups > 1 ? lstm_batch2_fn(Hl, groups, last_flags & UMX_FLAG_PRECISE_ACT)
-                                  : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
-    lstm_kernel_last = octets ? "lstm_batch8_kernel" : turned ? "lstm_batcht_kernel" : grouped ? "lstm_batchs_kernel" : groups > 1 ? "lstm_batch2_kernel" : "lstm_batch_kernel";
-    const int threads = groups > 1 && !grouped && !turned && !octets ? LSTMB2_THREADS : LSTM_THREADS;
-    const int Sw = octets ? 32 : (grouped || turned) ? 2 * (S / kBatchsSpan) : S; // workgroups per chain of the launch's grid
-    // the twelve-wave kernel of lstm_batch2.h takes the row sums but leaves the planes to split_planes_kernel
-    const bool writes_planes = fuse && lstm_writes_planes && (groups == 1 || grouped || turned || octets);
+    // ONE recurrence per context shape (round 6).  lstm_batch8.h (LSTM hidden 512 / 256, u8-resident W_hh): a launch serves the octets
+    // the chip holds side by side -- 32 lanes (hidden 1024) or 64 (hidden 512) --, twice that with two octets per workgroup in turn.
+    // Everything else: lstm_batch_kernel, a group of 16 lanes per launch.  More lanes than a launch serves: the parts one after the other
+    // (each a complete layer of its lanes: per (unit, lane) the arithmetic does not know who else is in the context).
+    const bool octets = lstm_batch8_ok;
+    const int per = octets ? LSTM8_TRACKS * lstm8_octets(Hl) : LSTMB_GROUP_TRACKS;
+    const int octs = octets && env_lstm8_paired && top > per ? 2 : 1; // octets per workgroup, in turn (UMX_LSTM8_PAIRED=0: two launches instead)
+    const int span = per * octs, parts = (top + span - 1) / span;
+    a.nbp = octets ? 16 : std::min(top, span) > 8 ? 16 : std::min(top, span) > 4 ? 8 : std::min(top, span) > 2 ? 4 : std::min(top, span) > 1 ? 2 : 1;
+    a.bulk = a.nbp > 8 ? 8 : 16;
+    const size_t lds = octets ? lstm8_lds_bytes(Hl, octs) : lstmb_lds_bytes(a.nbp, a.bulk);
+    const void *fn = octets ? lstm_batch8_fn(Hl, last_flags & UMX_FLAG_PRECISE_ACT, octs) : lstm_batch_fn(Hl, wq, last_flags & UMX_FLAG_PRECISE_ACT);
+    lstm_kernel_last = octets ? "lstm_batch8_kernel" : "lstm_batch_kernel";
+    const int threads = LSTM_THREADS;
+    const int Sw = octets ? 32 : S; // workgroups per chain of the launch's grid
+    const bool writes_planes = fuse && lstm_writes_planes;
     if (!writes_planes)
         for (int i = 0; i < 4; ++i)
             a.planes[i] = nullptr;
@@ -193,16 +184,17 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
     sl.lstm_wrote_planes[layer] = writes_planes;
     sl.lstm_rows_f32[layer] = !writes_planes || a.write_f32;
     void *kargs[] = {&a};
-    // lstm_batch8.h with one octet per workgroup serves 32 lanes per launch: 33 .. 64 lanes as two halves one after the other
-    // (UMX_LSTM8_PAIRED=0; the default is one launch of two octets per workgroup in turn)
-    const int halves = octets && octs == 1 && top > LSTM8_OCTETS * LSTM8_TRACKS ? 2 : 1;
-    auto half_on = [&](int hf) { return halves == 1 || ((lane_mask >> (32 * hf)) & 0xffffffffull) != 0; };
+    auto part_on = [&](int p) {
+        const unsigned long long m = span >= 64 ? ~0ull : ((1ull << span) - 1ull);
+        return ((lane_mask >> (span * p)) & m) != 0;
+    };
     bool persistent = !stepwise && persistent_ok && 8 * S <= lstm_batch_capacity;
-    for (int hf = 0; persistent && hf < halves; ++hf)
+    int queued = 0;
+    for (int p = 0; persistent && p < parts; ++p)
     {
-        if (!half_on(hf))
+        if (!part_on(p))
             continue;
-        a.lane_base = 32 * hf;
+        a.lane_base = span * p;
         a.tag_epoch = next_tag_base() >> 12; // unique per launch (20 bits); the granule area is cleared when it wraps
         const bool clear = tag_epoch == 0;
         a.t_begin = 0;
@@ -216,8 +208,15 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
         {
             (void)hipGetLastError();
             persistent_ok = false;
-            persistent = false; // (nothing of this layer has run: the first half's launch is the one that can be refused)
+            persistent = false;
+            if (queued > 0) // an earlier part of this layer is already on the stream: re-running the layer per step would advance its lanes twice
+            {
+                set_error(std::string("batched LSTM: launch of a later part of a layer refused: ") + hipGetErrorString(e));
+                return UMX_ERR_HIP;
+            }
         }
+        else
+            ++queued;
     }
     if (!persistent)
     {
@@ -236,10 +235,10 @@ int umx_hip_ctx::run_lstm_layer_batched(Slot &sl, int layer, const int *active, 
             a.t_end = step + 1;
             a.state = (step & 1) ? state_alt : state;
             a.state_out = (step & 1) ? state : state_alt;
-            for (int hf = 0; hf < halves; ++hf)
-                if (half_on(hf))
+            for (int p = 0; p < parts; ++p)
+                if (part_on(p))
                 {
-                    a.lane_base = 32 * hf;
+                    a.lane_base = span * p;
                     UMX_HIP_CHECK(hipLaunchKernel(fn, dim3(2 * nact * Sw), dim3(threads), kargs, lds, st));
                 }
         }

@@ -167,7 +167,7 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_kernel(S
             xs[it][j] = 0.f;
         if (k < a.cols && live)
         {
-            const float4 v0 = *reinterpret_cast<const float4 *>(src + k), v1 = *reinterpret_cast<const float4 *>(src + k + 4);
+            const float4 v0 = stream_load4(src + k), v1 = stream_load4(src + k + 4); // (an activation row is split once)
             xs[it][0] = v0.x; xs[it][1] = v0.y; xs[it][2] = v0.z; xs[it][3] = v0.w;
             xs[it][4] = v1.x; xs[it][5] = v1.y; xs[it][6] = v1.z; xs[it][7] = v1.w;
             if (sc)
@@ -215,8 +215,8 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_kernel(S
         {
             uint4 p1, p2;
             split2_f16(xs[it], scale, p1, p2);
-            *reinterpret_cast<uint4 *>(dst + k) = p1;
-            *reinterpret_cast<uint4 *>(dst + a.plane + k) = p2;
+            stream_store4u(reinterpret_cast<uint4 *>(dst + k), p1); // (gigabytes per launch: gone from the L2s long before the GEMM asks)
+            stream_store4u(reinterpret_cast<uint4 *>(dst + a.plane + k), p2);
         }
     }
 }
@@ -241,7 +241,7 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_shared_k
             x[it][j] = 0.f;
         if (k < a.cols && live)
         {
-            const float4 v0 = *reinterpret_cast<const float4 *>(src + k), v1 = *reinterpret_cast<const float4 *>(src + k + 4);
+            const float4 v0 = stream_load4(src + k), v1 = stream_load4(src + k + 4); // (an activation row is split once)
             x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
             x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
         }
@@ -295,8 +295,8 @@ template <int ITER> __global__ __launch_bounds__(256) void split_planes_shared_k
             {
                 uint4 p1, p2;
                 split2_f16(xs[it], scale, p1, p2);
-                *reinterpret_cast<uint4 *>(dst + k) = p1;
-                *reinterpret_cast<uint4 *>(dst + a.plane + k) = p2;
+                stream_store4u(reinterpret_cast<uint4 *>(dst + k), p1);
+                stream_store4u(reinterpret_cast<uint4 *>(dst + a.plane + k), p2);
             }
         }
     }

@@ -41,7 +41,7 @@ namespace umx
 {
 
 static_assert(MAX_TRACK_LANES == 64, "common.h LaneSet covers every track lane of a context");
-constexpr int LSTMB_MAX_TRACKS = 64;  // track lanes per context: 16 per launch of lstm_batch_kernel, 17 .. 32 side by side (lstm_batchs_kernel), 33 .. 64 as two such pairs in turn (lstm_batcht_kernel)
+constexpr int LSTMB_MAX_TRACKS = 64;  // track lanes per context: 16 per launch of lstm_batch_kernel (more: one launch per group of 16), 32 / 64 per launch of lstm_batch8_kernel
 constexpr int LSTMB_GROUP_TRACKS = 16; // the matrix instruction's N
 // x64 shader cycles a wave sleeps before its first poll of a step.  A wave that also runs the gate phase has just
 // published and needs one hand-off latency; the other waves come straight from the barrier and have the whole gate
@@ -153,8 +153,8 @@ template <int NDW> __device__ __forceinline__ float2v tree_sum2(const float2v (&
 // the pair sums (h1 + h2) + (h1' + h2') travelling in the granules' free fourth dword, added by the consumer and folded over the
 // four 8-unit groups with two lane exchanges: 20 % fewer matrix-pipe cycles, 1.5 % SLOWER -- two dependent lane exchanges on the
 // turn's critical path cost more than four queued matrix instructions on an idle pipe.  Removed in round 4; the dword is zero.)
-// SP = slice span: the workgroup owns SP x 16 hidden units = SP x 64 gate columns (SP = 1: the form described above; SP = 2,
-// round 4: lstm_batchs_kernel below -- eight M tiles, every wave also a gate wave).  group: the workgroup serves lanes
+// SP = slice span: the workgroup owns SP x 16 hidden units = SP x 64 gate columns (SP = 1: the form described above, the only one
+// instantiated since round 6; SP = 2 was round 4's side-by-side kernel -- eight M tiles, every wave also a gate wave).  group: the workgroup serves lanes
 // [16 group, 16 group + 16) of the launch, with a granule area of their own.
 template <int HL, bool WQ, bool FAST, bool PRECISE, int SP = 1>
 __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int slice, unsigned char *smem, int *abort_flag, int group = 0)
@@ -169,7 +169,7 @@ __device__ __forceinline__ void lstmb_body(const LstmBArgs &a, int chain, int sl
     const int target = a.tmap[chain >> 1], dir = chain & 1, wchain = target * 2 + dir;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, q = l >> 4;
     const int nbp = SP > 1 ? LSTMB_GROUP_TRACKS : a.nbp, bulk = a.bulk, ring_mask = 2 * bulk - 1, T = a.T, S = a.S;
-    const unsigned lane_mask = SP > 1 ? ((unsigned)(a.lane_mask >> lane0) & 0xffffu) : (unsigned)a.lane_mask;
+    const unsigned lane_mask = (unsigned)(a.lane_mask >> lane0) & 0xffffu;
     const bool lane_on = (lane_mask >> n) & 1u;
     const bool dot_wave = w < NDW, gate_wave = w < MT; // gate wave w finishes M tile w (units 4w .. 4w+3 of the workgroup's)
     constexpr int RING_PITCH = LSTMB_RING_PITCH;
@@ -627,430 +627,15 @@ template <int HL, bool WQ, bool PRECISE> __global__ __launch_bounds__(LSTM_THREA
     const int chain = s_ctl[0], slice = s_ctl[1];
     if (s_ctl[3] || chain >= a.nchains)
         return;
+    // the launch serves the group of 16 lanes that starts at lane_base (contexts of more than 16 lanes that lstm_batch8.h does not
+    // take -- hidden 128 / 256, fp32-resident W_hh -- run their groups one launch after the other: engine_lstm.h)
+    const int group = a.lane_base / LSTMB_GROUP_TRACKS;
     if (s_ctl[2])
-        lstmb_body<HL, WQ, true, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3]);
+        lstmb_body<HL, WQ, true, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3], group);
     else
-        lstmb_body<HL, WQ, false, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3]);
+        lstmb_body<HL, WQ, false, PRECISE>(a, chain, slice, lstmb_smem, &s_ctl[3], group);
 }
 
-// ---- more than 16 track lanes (round 4): every GROUP of 16 lanes gets a part of the chip to itself.
-// What a step of the recurrence costs is the hand-off: every workgroup of a chain reads the whole h of its chain, for every lane it
-// serves -- 512 units x 16 lanes x 16-byte granules (8 bytes of payload) = 65.5 KB per group and step.  lstm_batch2.h runs the groups
-// of 16 lanes through all 256 workgroups IN TURN: 256 x 2 x 65.5 KB = 33.5 MB cross the L2s per step, ~10 TB/s at the measured 3.3 us --
-// more than half of what the L2 -> CU path delivers for this access width (tools/lds_probe: ~18 TB/s), so the polls' "round trip" is
-// mostly transfer time, and splitting the same work over independent four-wave workgroups (tried first this round: groups as
-// chains of their own, two workgroups per CU, the same bytes) ran the same 3.4 us.  Fewer readers is what cuts the bytes: here a
-// chain is 16 workgroups of SP = 2 slices (32 hidden units = 128 gate columns, eight M tiles; twice the matrix instructions and
-// registers per wave, every wave a gate wave), a group's eight chains take 128 CUs, and TWO groups sit side by side on the chip:
-// 256 x 65.5 KB = 16.8 MB per step for the same 32 lanes.  Arithmetic per (unit, lane): lstmb_body's, unchanged -- the bits of
-// lstm_batch_kernel.  Census: every XCD must receive G x S / SP workgroups (32 = one per CU); ticket / (S / SP) picks one of the
-// XCD's G chains, ticket % (S / SP) the slice; chains are numbered so that a (group, chain) pair lives on ONE XCD.
-template <int HL, bool PRECISE, int G> __global__ __launch_bounds__(LSTM_THREADS, 2) void lstm_batchs_kernel(LstmBArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lstmbs_smem[];
-    __shared__ int s_ctl[4]; // chain, slice (or ticket), fast, abort
-    constexpr int SP = 2;
-    const int tid = threadIdx.x, SW = a.S / SP; // workgroups per chain
-    if (tid == 0)
-    {
-        if (a.census)
-            lstm_census(a.sync, a.status, G * SW, (int)gridDim.x, a.force_safe, s_ctl);
-        else
-        {
-            s_ctl[2] = 0;
-            s_ctl[3] = 0;
-        }
-    }
-    __syncthreads();
-    if (s_ctl[3])
-        return;
-    int vc, slice; // virtual chain = group x 8 + chain
-    if (s_ctl[2])
-    {
-        vc = s_ctl[0] * G + s_ctl[1] / SW; // XCD x holds the virtual chains x G .. x G + G - 1
-        slice = s_ctl[1] % SW;
-    }
-    else // static roles: the grid is G x (chains of the launch) x S / SP; virtual chains in blocks of `nch` per group
-    {
-        const int nch = (int)gridDim.x / (G * SW), v = (int)blockIdx.x / SW;
-        vc = (v / nch) * 8 + v % nch;
-        slice = (int)blockIdx.x % SW;
-    }
-    const int group = vc >> 3, chain = vc & 7;
-    const unsigned gmask = (unsigned)(a.lane_mask >> (LSTMB_GROUP_TRACKS * group)) & 0xffffu;
-    if (chain >= a.nchains || gmask == 0u)
-        return;
-    if (s_ctl[2])
-        lstmb_body<HL, true, true, PRECISE, SP>(a, chain, slice, lstmbs_smem, &s_ctl[3], group);
-    else
-        lstmb_body<HL, true, false, PRECISE, SP>(a, chain, slice, lstmbs_smem, &s_ctl[3], group);
-}
-
-// ---- 33 .. 64 track lanes (round 5): two side-by-side PAIRS of groups IN TURN through the workgroups of lstm_batchs_kernel.
-// A workgroup serves lane group g (turn 0) and lane group g + G (turn 1) with the SAME weight fragments: while the granules of
-// turn 0's step travel through the L2 to the other workgroups, the workgroup runs turn 1's step, and vice versa -- a group's
-// hand-off wait disappears behind the other group's matrix and gate phases (the polls of a turn find their data published a
-// whole turn ago).  Per (unit, lane) the arithmetic is lstmb_body<.., SP = 2>'s, instruction for instruction (same fragments,
-// same order of matrix instructions, same tree over the eight k-ranges): bit-identical to the other batched kernels.
-// The partial sums' two LDS buffers alternate by TURN (a turn's gate reads end before the next turn's barrier, which every wave
-// passes before it writes that buffer again); granule areas, state, rows and planes are per lane group as before.
-template <int HL, bool FAST, bool PRECISE, int NT>
-__device__ __forceinline__ void lstmb_body_turns(const LstmBArgs &a, int chain, int slice, unsigned char *smem, int *abort_flag, int group0, int group_stride)
-{
-    constexpr int SP = 2, NKS = HL / 32, KSW = NKS / 8, NDW = 8, MT = 4 * SP, nbp = LSTMB_GROUP_TRACKS;
-    static_assert(NKS >= 8 && NT == 2, "eight multiply waves, two turns");
-    const int target = a.tmap[chain >> 1], dir = chain & 1, wchain = target * 2 + dir;
-    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, q = l >> 4;
-    const int T = a.T, S = a.S;
-    float4 *part = reinterpret_cast<float4 *>(smem); // [2][8 waves][MT tiles][4 q][nbp]
-    // sum_k h'_k per k-range and lane: [turn][step parity][8 waves][16] -- written by step t's matrix phase, read by wave 7 during step
-    // t + 1's polls, when other waves may already be in step t + 1's matrix phase: per turn AND per step parity (the launch adds
-    // LSTMB_HSW_BYTES to lstmb_lds_bytes for the second turn)
-    float *const hsw = reinterpret_cast<float *>(smem + lstmb_lds_bytes(nbp, a.bulk, SP) - LSTMB_HSW_BYTES);
-
-    // ---- W_hh fragments (shared by the turns): lane (i = l & 15, q) of tile mt holds gate column 16 mt + i, units k = 32 ks' + 8 q + j
-    f16x8 Wf[MT][KSW];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int ks = 0; ks < KSW; ++ks)
-        {
-            const size_t base = (((size_t)wchain * S + slice * SP + (mt >> 2)) * HL + (size_t)(w * KSW + ks) * 32 + 8 * q) * 64 + 16 * (mt & 3) + n;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                Wf[mt][ks][j] = (_Float16)((float)a.Wq[base + (size_t)j * 64] - 128.0f);
-        }
-    constexpr float HSCALE = 16384.0f;
-    const float wsc = a.wsc[wchain] * (1.0f / HSCALE), wof2 = (a.wof[wchain] + 128.0f * a.wsc[wchain]) * (1.0f / HSCALE);
-    const int unit = slice * 16 * SP + 4 * w + q; // gate wave w finishes M tile w
-    const float4 bh = *reinterpret_cast<const float4 *>(a.bhh + ((size_t)wchain * S + slice * SP + (w >> 2)) * 64 + 4 * (4 * (w & 3) + q));
-    gu32 *status = (gu32 *)a.status;
-    const size_t ldp = (size_t)a.ldp, ldo = (size_t)a.ldo;
-    const unsigned tag_hi = a.tag_epoch << 12;
-    const int t_begin = a.t_begin, t_end = a.t_end;
-    const size_t plane_elems = a.plane_elems, ldpl = (size_t)a.ldpl;
-
-    // ---- per turn: the lane group's state
-    bool lane_on[NT], turn_on[NT];
-    unsigned gmask[NT];
-    float c[NT], hlast[NT];
-    unsigned plast[NT];
-    float4 p4n[NT];
-    __amdgpu_buffer_rsrc_t gran_rs[NT];
-    float *outp[NT], *rsp[NT];
-    unsigned short *plp[NT];
-    const float *Pg[NT];
-    size_t st_h[NT], st_c[NT];
-#pragma unroll
-    for (int tr = 0; tr < NT; ++tr)
-    {
-        const int group = group0 + tr * group_stride, lane0 = LSTMB_GROUP_TRACKS * group;
-        gmask[tr] = (unsigned)(a.lane_mask >> lane0) & 0xffffu;
-        turn_on[tr] = gmask[tr] != 0u; // workgroup-uniform
-        lane_on[tr] = (gmask[tr] >> n) & 1u;
-        st_h[tr] = (size_t)(lane0 + n) * a.state_stride + state_off(target, a.layer, dir, 0, HL);
-        st_c[tr] = (size_t)(lane0 + n) * a.state_stride + state_off(target, a.layer, dir, 1, HL);
-        c[tr] = lane_on[tr] ? a.state[st_c[tr] + unit] : 0.f;
-        hlast[tr] = lane_on[tr] ? a.state[st_h[tr] + unit] : 0.f;
-        plast[tr] = 0u;
-        gran_rs[tr] = __builtin_amdgcn_make_buffer_rsrc(a.sync + LSTM_SYNC_HEADER_WORDS + (size_t)group * lstmb_granule_words(HL), 0,
-                                                        (int)(lstmb_granule_words(HL) * 4), 0x00020000);
-        outp[tr] = a.out[target] + (size_t)(lane0 + n) * a.out_stride + a.col0 + dir * HL + unit;
-        plp[tr] = a.planes[target] ? a.planes[target] + (size_t)(lane0 + n) * a.Tp * a.ldpl + a.col0 + dir * HL + unit : nullptr;
-        rsp[tr] = (a.rs_dir[target] && slice == 0) ? a.rs_dir[target] + (size_t)dir * a.rs_rows + (size_t)lane0 * a.Tp : nullptr;
-        Pg[tr] = a.P[target] + (size_t)(lane0 + n) * a.p_stride + ((size_t)dir * S + slice * SP + (w >> 2)) * 64 + 4 * (4 * (w & 3) + q);
-        p4n[tr] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane_on[tr] && t_begin < t_end)
-            p4n[tr] = *reinterpret_cast<const float4 *>(Pg[tr] + (size_t)(dir == 0 ? t_begin : T - 1 - t_begin) * ldp);
-    }
-    // which of the two LDS buffers (partial sums, k-range sums of h') a turn uses: they alternate by TURN when the workgroup runs
-    // both turns, by STEP when one of its lane groups is empty (33 .. 48 lanes: then a step has one barrier, as in lstmb_body)
-    const bool both_turns = turn_on[0] && turn_on[1];
-    auto buffer_of = [&](int tr, int st) __attribute__((always_inline)) { return both_turns ? (tr & 1) : (st & 1); };
-    // the row sum of the row that step `sm` of turn `tr` multiplied with: see lstmb_body
-    auto row_sum_of_step = [&](int tr, int sm) __attribute__((always_inline)) {
-        if (rsp[tr] && w == NDW - 1 && l < nbp && sm > 0 && ((gmask[tr] >> l) & 1u))
-        {
-            float hp[8];
-#pragma unroll
-            for (int ww = 0; ww < NDW; ++ww)
-                hp[ww] = hsw[(((tr & 1) * 2 + (sm & 1)) * 8 + ww) * 16 + l];
-            rsp[tr][(size_t)l * a.Tp + (size_t)(dir == 0 ? sm - 1 : T - sm)] = tree_sum<NDW>(hp) * (1.0f / 16384.0f);
-        }
-    };
-    __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): see lstmb_body
-    __syncthreads();
-    const bool prof = a.prof != nullptr && group0 == 0 && chain == 0 && slice == 0 && (w == 0 || w == LSTMB_PROF_WAVE);
-    const int pw_idx = w == 0 ? 0 : 1;
-    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0};
-    unsigned prof_spins = 0;
-    const f16x8 ones16 = __builtin_bit_cast(f16x8, make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u));
-
-    for (int step = t_begin; step < t_end; ++step)
-    {
-        if (a.abort_at && step == a.abort_at && tid == 0)
-        {
-            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *abort_flag = 1;
-        }
-#pragma unroll
-        for (int tr = 0; tr < NT; ++tr)
-        {
-            if (!turn_on[tr]) // (workgroup-uniform: every wave skips the turn's barrier alike)
-                continue;
-            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            if (prof)
-                c0 = clock64();
-            float4 p4s = make_float4(0.f, 0.f, 0.f, 0.f);
-            f16x8 hf[KSW][2];
-            if (step > t_begin)
-            {
-                const unsigned want = tag_hi | (unsigned)step;
-                int goff[KSW];
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks)
-                    goff[ks] = (int)(lstmb_granule_index((step - 1) & 1, chain, (w * KSW + ks) * 32 + 8 * q, n, HL, nbp) * 16);
-                uint4 v[KSW][4];
-                unsigned spins = 0;
-                for (;;)
-                {
-                    bool ok = true;
-                    if (lane_on[tr])
-                    {
-#pragma unroll
-                        for (int ks = 0; ks < KSW; ++ks)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                v[ks][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(gran_rs[tr], goff[ks] + i * 64 * nbp, 0, 16)); // sc1
-                        if (spins == 0)
-                            row_sum_of_step(tr, step - 1);
-                        unsigned bad = 0;
-#pragma unroll
-                        for (int ks = 0; ks < KSW; ++ks)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                bad |= v[ks][i].x ^ want;
-                        ok = bad == 0;
-                    }
-                    if (__all(ok))
-                        break;
-                    if (++spins > LSTM_SPIN_LIMIT ||
-                        ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
-                    {
-                        if (l == 0)
-                            __hip_atomic_store(status, 1u + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        *abort_flag = 1;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(LSTMB_RETRY_SLEEP);
-                }
-                prof_spins = spins;
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks)
-                {
-                    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-                    const uint4 g0 = lane_on[tr] ? v[ks][0] : z, g1 = lane_on[tr] ? v[ks][1] : z, g2 = lane_on[tr] ? v[ks][2] : z, g3 = lane_on[tr] ? v[ks][3] : z;
-                    hf[ks][0] = __builtin_bit_cast(f16x8, make_uint4(g0.y, g1.y, g2.y, g3.y));
-                    hf[ks][1] = __builtin_bit_cast(f16x8, make_uint4(g0.z, g1.z, g2.z, g3.z));
-                }
-            }
-            else
-            {
-                // h_{t_begin - 1} from the fp32 stream state, split like a published granule
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks)
-                {
-                    float hv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        hv[j] = lane_on[tr] ? a.state[st_h[tr] + (w * KSW + ks) * 32 + 8 * q + j] : 0.f;
-                    uint4 p1, p2;
-                    split2_f16(hv, HSCALE, p1, p2);
-                    hf[ks][0] = __builtin_bit_cast(f16x8, p1);
-                    hf[ks][1] = __builtin_bit_cast(f16x8, p2);
-                }
-            }
-            if (prof)
-                c1 = clock64();
-            p4s = p4n[tr]; // row `step`, requested a step ago
-            if (lane_on[tr] && step + 1 < t_end)
-                p4n[tr] = *reinterpret_cast<const float4 *>(Pg[tr] + (size_t)(dir == 0 ? step + 1 : T - 2 - step) * ldp);
-            floatx4 acc[MT];
-            floatx4 accH = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-            // smaller term first (the order of lstmb_body's u8-resident form)
-#pragma unroll
-            for (int ph = 1; ph >= 0; --ph)
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[mt][ks], hf[ks][ph], acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int ph = 1; ph >= 0; --ph)
-#pragma unroll
-                for (int ks = 0; ks < KSW; ++ks)
-                    accH = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones16, hf[ks][ph], accH, 0, 0, 0);
-            const float hsum_wave = accH[0];
-            const int pbuf = buffer_of(tr, step);
-            if (rsp[tr] && q == 0)
-                hsw[(((tr & 1) * 2 + (step & 1)) * 8 + w) * 16 + n] = hsum_wave;
-            {
-                float4 *pw = part + ((size_t)((pbuf * 8 + w) * MT) * 4 + q) * nbp + n;
-                const float hs = wof2 * hsum_wave;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    pw[(size_t)mt * 4 * nbp] = make_float4(wsc * acc[mt][0] + hs, wsc * acc[mt][1] + hs, wsc * acc[mt][2] + hs, wsc * acc[mt][3] + hs);
-            }
-            // the output row of the PREVIOUS step of this turn goes out here, behind the polls (lstmb_body)
-            if (lane_on[tr] && step > t_begin)
-            {
-                const size_t fr = (size_t)(dir == 0 ? step - 1 : T - step);
-                if (!plp[tr] || a.write_f32)
-                    outp[tr][fr * ldo] = hlast[tr];
-                if (plp[tr])
-                {
-                    plp[tr][fr * ldpl] = (unsigned short)(plast[tr] & 0xffffu);
-                    plp[tr][plane_elems + fr * ldpl] = (unsigned short)(plast[tr] >> 16);
-                }
-            }
-            if (prof)
-                c2 = clock64();
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS only
-            if (*abort_flag)
-                return;
-            if (prof)
-                c3 = clock64();
-            {
-                float2v pa[8], pb[8];
-#pragma unroll
-                for (int ww = 0; ww < NDW; ++ww)
-                {
-                    const float4 v4 = part[((size_t)(((pbuf * 8 + ww) * MT + w) * 4) + q) * nbp + n];
-                    pa[ww] = float2v{v4.x, v4.y};
-                    pb[ww] = float2v{v4.z, v4.w};
-                }
-                const float2v sa = tree_sum2<NDW>(pa), sb = tree_sum2<NDW>(pb);
-                const float pre_i = (p4s.x + sa.x) + bh.x, pre_f = (p4s.y + sa.y) + bh.y, pre_g = (p4s.z + sb.x) + bh.z, pre_o = (p4s.w + sb.y) + bh.w;
-                float i_t, f_t, g_t, o_t;
-                if (PRECISE)
-                {
-                    i_t = sigmoid_ref(pre_i);
-                    f_t = sigmoid_ref(pre_f);
-                    g_t = tanhf(pre_g);
-                    o_t = sigmoid_ref(pre_o);
-                }
-                else
-                {
-                    i_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_i));
-                    f_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_f));
-                    g_t = tanh_hw(pre_g);
-                    o_t = __builtin_amdgcn_rcpf(1.0f + exp_hw(-pre_o));
-                }
-                const float c_t = f_t * c[tr] + i_t * g_t; // lstm.cpp:154-156
-                const float h = o_t * (PRECISE ? tanhf(c_t) : tanh_hw(c_t)); // lstm.cpp:157
-                const float hs14 = h * HSCALE;
-                const _Float16 h1 = (_Float16)hs14, h2 = (_Float16)(hs14 - (float)h1);
-                const unsigned b1 = __builtin_bit_cast(unsigned short, h1), b2 = __builtin_bit_cast(unsigned short, h2);
-                const unsigned mine12 = b1 | (b2 << 16);
-                const unsigned other12 = __builtin_amdgcn_permlane16_swap(mine12, mine12, false, false)[1];
-                if (lane_on[tr])
-                {
-                    c[tr] = c_t;
-                    hlast[tr] = h;
-                    plast[tr] = mine12;
-                    if ((q & 1) == 0)
-                    {
-                        const uint4 gv = make_uint4(tag_hi | (unsigned)(step + 1), b1 | (other12 << 16), (mine12 >> 16) | (other12 & 0xffff0000u), 0u);
-                        granule_store16<FAST>(gran_rs[tr], (int)(lstmb_granule_index(step & 1, chain, unit, n, HL, nbp) * 16), gv);
-                    }
-                }
-            }
-            if (prof && tr == 0)
-            {
-                const long long c4 = clock64();
-                pc[0] += (unsigned long long)(c1 - c0);
-                pc[1] += (unsigned long long)(c2 - c1);
-                pc[2] += (unsigned long long)(c3 - c2);
-                pc[3] += (unsigned long long)(c4 - c3);
-                pc[4] += 1;
-                pc[5] += prof_spins;
-            }
-        }
-    }
-#pragma unroll
-    for (int tr = 0; tr < NT; ++tr)
-    {
-        if (!turn_on[tr])
-            continue;
-        if (t_end > t_begin)
-            row_sum_of_step(tr, t_end - 1);
-        if (lane_on[tr])
-        {
-            if (t_end > t_begin)
-            {
-                const size_t fr = (size_t)(dir == 0 ? t_end - 1 : T - t_end);
-                outp[tr][fr * ldo] = hlast[tr];
-                if (plp[tr])
-                {
-                    plp[tr][fr * ldpl] = (unsigned short)(plast[tr] & 0xffffu);
-                    plp[tr][plane_elems + fr * ldpl] = (unsigned short)(plast[tr] >> 16);
-                }
-            }
-            a.state_out[st_h[tr] + unit] = hlast[tr];
-            a.state_out[st_c[tr] + unit] = c[tr];
-        }
-    }
-    if (prof && l == 0)
-        for (int i = 0; i < 6; ++i)
-            a.prof[(a.layer * 2 + pw_idx) * 8 + i] = (t_begin == 0 ? 0ull : a.prof[(a.layer * 2 + pw_idx) * 8 + i]) + pc[i];
-}
-
-// grid as lstm_batchs_kernel<.., G = 2>: the workgroup of (group g, chain, slice) serves the lane groups g and g + 2
-template <int HL, bool PRECISE, int NT> __global__ __launch_bounds__(LSTM_THREADS, 2) void lstm_batcht_kernel(LstmBArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lstmbt_smem[];
-    __shared__ int s_ctl[4];
-    constexpr int SP = 2, G = 2;
-    const int tid = threadIdx.x, SW = a.S / SP;
-    if (tid == 0)
-    {
-        if (a.census)
-            lstm_census(a.sync, a.status, G * SW, (int)gridDim.x, a.force_safe, s_ctl);
-        else
-        {
-            s_ctl[2] = 0;
-            s_ctl[3] = 0;
-        }
-    }
-    __syncthreads();
-    if (s_ctl[3])
-        return;
-    int vc, slice;
-    if (s_ctl[2])
-    {
-        vc = s_ctl[0] * G + s_ctl[1] / SW;
-        slice = s_ctl[1] % SW;
-    }
-    else
-    {
-        const int nch = (int)gridDim.x / (G * SW), v = (int)blockIdx.x / SW;
-        vc = (v / nch) * 8 + v % nch;
-        slice = (int)blockIdx.x % SW;
-    }
-    const int group = vc >> 3, chain = vc & 7;
-    unsigned any = 0;
-    for (int tr = 0; tr < NT; ++tr)
-        any |= (unsigned)(a.lane_mask >> (LSTMB_GROUP_TRACKS * (group + G * tr))) & 0xffffu;
-    if (chain >= a.nchains || any == 0u)
-        return;
-    if (s_ctl[2])
-        lstmb_body_turns<HL, true, PRECISE, NT>(a, chain, slice, lstmbt_smem, &s_ctl[3], group, G);
-    else
-        lstmb_body_turns<HL, false, PRECISE, NT>(a, chain, slice, lstmbt_smem, &s_ctl[3], group, G);
-}
 
 // The row sums of the ONE row per direction that no later step multiplies with (the launch's last step: frame T - 1 of the forward
 // chain, frame 0 of the backward chain): sum_k of the two fp16 planes of h_k * 2^14 -- formed here from the fp32 row exactly as the

@@ -8,7 +8,7 @@
 // Here a workgroup serves an OCTET of 8 lanes and owns 64 hidden units = 256 gate columns of its chain; a chain of a 32-lane
 // launch is 8 column shards x 4 octets = 32 workgroups as before (one per CU, 256 in all), but
 //   * a workgroup needs h of its own 8 lanes only: 512 units x 8 lanes = 2,048 granules per step (12 of a granule's 16 bytes are
-//     loaded: 24 KB), and a granule is read by 8 workgroups instead of 16: under half of lstm_batchs_kernel's hand-off bytes;
+//     loaded: 24 KB), and a granule is read by 8 workgroups instead of 16: under half of the hand-off bytes of round 4's side-by-side kernel;
 //   * the matrix instruction's N = 16 is 8 lanes x the TWO fp16 planes of h * 2^14, so one v_mfma_f32_16x16x32_f16 multiplies both
 //     planes; a wave owns 8 units = 32 gate columns = two M tiles for the WHOLE contraction (W_hh: 2 x 16 fragments = 128 VGPRs for
 //     the layer), so its accumulators ARE the gate pre-activations: no partial sums, no second hand-over of 80 KB through LDS;
@@ -32,7 +32,8 @@ namespace umx
 
 constexpr int LSTM8_TRACKS = 8;  // track lanes per workgroup
 constexpr int LSTM8_UNITS = 64;  // hidden units per workgroup (8 per wave)
-constexpr int LSTM8_OCTETS = 4;  // octets of a launch: 32 lanes
+// octets side by side in a launch = the virtual chains an XCD holds beside the 8 real ones: 32 workgroups per XCD / column shards per chain
+__host__ __device__ constexpr int lstm8_octets(int Hl) { return 32 / (Hl / LSTM8_UNITS); } // hidden 1024: 4 (32 lanes), hidden 512: 8 (64 lanes)
 #define LSTM8_RETRY_SLEEP 1 // x64 cycles between failed polls
 #define LSTM8_OOR 0x7ffffff0 // a buffer offset beyond every resource of this kernel: the store is dropped
 
@@ -78,7 +79,10 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
     constexpr int NLD = HL * 4 / 512;   // granules a thread polls per step
     constexpr int GPS = HL * 4;         // granules per (slot, chain): HL / 2 pairs x 8 tracks
     constexpr int HB = (HL / 32) * 4 * 16 * 16;         // = lstm8_h_bytes(HL)
-    static_assert(HL % 256 == 0 && (NO == 1 || NO == 2), "eight waves x 32-unit k-steps; one octet or two in turn");
+    constexpr int OCT = lstm8_octets(HL); // octets of a launch (NO = 2: the workgroup of octet o also serves octet o + OCT)
+    constexpr int EARLY = LSTM8_EARLY_KS < 0 ? 0 : (LSTM8_EARLY_KS < NKS ? LSTM8_EARLY_KS : NKS - 3); // k-step behind which the next turn's polls go out
+    constexpr int HS_KS = 3 < NKS ? 3 : NKS - 1; // k-step behind which a wave's k-range sum of h' is written (its KSW products are long done)
+    static_assert(HL % 256 == 0 && (NO == 1 || NO == 2) && 32 % (HL / LSTM8_UNITS) == 0 && NKS >= 8, "eight waves x 32-unit k-steps; one octet or two in turn");
     const int target = a.tmap[chain >> 1], dir = chain & 1, wchain = target * 2 + dir;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, n = l & 15, q = l >> 4;
     const int tr = n & 7, tile = n >> 3; // the cell this lane finishes: track tr of the octet, unit 4 tile + q of the wave's eight
@@ -143,7 +147,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
 #pragma unroll
     for (int o = 0; o < NO; ++o)
     {
-        const int octet = octet0 + o * LSTM8_OCTETS;
+        const int octet = octet0 + o * OCT;
         lane0[o] = a.lane_base + LSTM8_TRACKS * octet;
         const unsigned mask8 = (unsigned)(a.lane_mask >> lane0[o]) & 0xffu;
         on[o] = mask8 != 0u;
@@ -163,7 +167,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                                                        (int)lstm8_granule_bytes(HL), 0x00020000);
         p4n[o] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane_on[o] && t_begin < t_end)
-            p4n[o] = *reinterpret_cast<const float4 *>(Pg[o] + (size_t)(dir == 0 ? t_begin : T - 1 - t_begin) * ldp);
+            p4n[o] = stream_load4(Pg[o] + (size_t)(dir == 0 ? t_begin : T - 1 - t_begin) * ldp);
         // h_{t_begin - 1} from the fp32 stream state, split like a published granule; absent tracks are zero columns in both buffers
         const size_t sh = (size_t)(lane0[o] + p_tr) * a.state_stride + state_off(target, a.layer, dir, 0, HL);
 #pragma unroll
@@ -306,7 +310,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
             }
             const float4 p4 = p4n[o]; // row `step` of W_ih x + b_ih, requested a step ago
             if (!(LSTM8_EXPERIMENT & 1) && lane_on[o] && step + 1 < t_end)
-                p4n[o] = *reinterpret_cast<const float4 *>(Pg[o] + (size_t)(dir == 0 ? step + 1 : T - 2 - step) * ldp);
+                p4n[o] = stream_load4(Pg[o] + (size_t)(dir == 0 ? step + 1 : T - 2 - step) * ldp); // (a row of W_ih x + b_ih is read once)
             if (prof)
                 c1 = clock64();
             LSTM8_LDS_BARRIER(); // h_{step-1} is in LDS
@@ -325,7 +329,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                     const uint4 val = *reinterpret_cast<const uint4 *>(stg + ((o * 2 + w) * 8 + strk) * LSTM8_STG_PITCH + sgrp * 8);
                     unsigned short *dst = a.planes[target] + (size_t)w * plane_elems + ((size_t)(lane0[o] + strk) * a.Tp + (size_t)(dir == 0 ? step - 1 : T - step)) * ldpl +
                                           a.col0 + dir * HL + shard * LSTM8_UNITS + sgrp * 8;
-                    *reinterpret_cast<uint4 *>(dst) = val;
+                    stream_store4u(reinterpret_cast<uint4 *>(dst), val);
                 }
             }
             // the next turn's polls: the other octet's granules were published a turn ago
@@ -357,9 +361,9 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                     bf[ks % LSTM8_FRAG_AHEAD] = *reinterpret_cast<const f16x8 *>(fb + (ks + LSTM8_FRAG_AHEAD) * 1024);
                 if (LSTM8_PIN_ORDER)
                     __builtin_amdgcn_sched_barrier(0); // the order as written: two matrix instructions, the read LSTM8_FRAG_AHEAD k-steps ahead
-                if (ks == 3) // (every row of accH holds the same sums; column n: plane n / 8 of track n % 8)
+                if (ks == HS_KS) // (every row of accH holds the same sums; column n: plane n / 8 of track n % 8)
                     hs[tr * 8 + w] = accH[0] + __int_as_float(dpp_row_ror<8>(__float_as_int(accH[0])));
-                if (NO > 1 && ks == (LSTM8_EARLY_KS < 0 ? 0 : LSTM8_EARLY_KS))
+                if (NO > 1 && ks == EARLY)
                 {
 #pragma unroll
                     for (int i = 0; i < NLD; ++i)
@@ -488,7 +492,7 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
 // grid: persistent (census = 1) 8 chains x 32 workgroups -- every XCD must receive 32 (one per CU): ticket / (HL / 64) picks one of the
 // XCD's virtual chains (octet, chain), ticket % (HL / 64) the column shard, so that a hand-off domain lives on ONE XCD;
 // one step per launch (census = 0): static roles, grid = octets x chains of the launch x shards.  NO = 2: the workgroup of octet o also
-// serves octet o + 4 (launches of 33 .. 64 lanes).
+// serves octet o + lstm8_octets (hidden 1024: launches of 33 .. 64 lanes; hidden 512 has its 64 lanes side by side).
 template <int HL, bool PRECISE, int NO> __global__ __launch_bounds__(LSTM_THREADS, 2) void lstm_batch8_kernel(LstmBArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lstm8_smem[];
@@ -523,7 +527,7 @@ template <int HL, bool PRECISE, int NO> __global__ __launch_bounds__(LSTM_THREAD
     const int octet = vc >> 3, chain = vc & 7;
     unsigned mask = (unsigned)(a.lane_mask >> (a.lane_base + LSTM8_TRACKS * octet)) & 0xffu;
     if (NO > 1)
-        mask |= (unsigned)(a.lane_mask >> (a.lane_base + LSTM8_TRACKS * (octet + LSTM8_OCTETS))) & 0xffu;
+        mask |= (unsigned)(a.lane_mask >> (a.lane_base + LSTM8_TRACKS * (octet + lstm8_octets(HL)))) & 0xffu;
     if (chain >= a.nchains || mask == 0u)
         return;
     if (s_ctl[2])

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void stft_kernel(StftIn in, int N, int T,
         const float2 dd = csub(zk, zn);
         const float2 sR = make_float2(dd.y * 0.5f, -dd.x * 0.5f); // (zk - zn) / (2i)
         const size_t iL = ((size_t)0 * T + f) * NBINS + k, iR = ((size_t)1 * T + f) * NBINS + k;
-        spec[iL] = sL;
-        spec[iR] = sR;
+        stream_store2(spec + iL, sL); // read next by the Wiener kernels, a whole network later
+        stream_store2(spec + iR, sR);
         if (k < CROP) // |X| (inference.cpp:29 abs()) is kept only where the network reads it; the Wiener kernels that need
         {             // it for every bin have the spectrogram in registers anyway and form it again (mix_magnitude, common.h)
             x[(size_t)f * KX + k] = mix_magnitude(sL);
