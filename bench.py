@@ -592,6 +592,10 @@ def main():
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"value": None, "error": repr(e)}
         if args.track_seconds > 0:
+            # what a umx-cli user sees (umx.cpp:99-295 on ONE GPU): a whole track through umx_hip_shift_inference, host buffers in and out.
+            # carry = the reference's semantics (one lstm_data through the segments: the one-track engine, segments pipelined);
+            # reset = UMX_FLAG_RESET_SEGMENTS, a DECLARED deviation (every segment from a zero state: the track's segments ride as
+            # the lanes of one call of a 16-lane context) -- with the SDR of its stems against carry mode's next to the time.
             e1 = make_engine(1, False)
             Lt = int(args.track_seconds * 44100)
             twave = pkg.ggml.synth_audio(Lt, 99)
@@ -599,11 +603,27 @@ def main():
             touts = [np.empty(2 * Lt, np.float32) for _ in range(4)]
             e1.separate_interleaved(ta, Lt, touts, shift_offset=4033)  # warm-up: allocates the track buffers
             best = min(e1.separate_interleaved(ta, Lt, touts, shift_offset=4033) for _ in range(3))
+            nseg = -(-(Lt + 22050 - 4033) // int(0.75 * N))
             line["track"] = {"seconds_of_audio": args.track_seconds, "wall_ms": round(best * 1e3, 2),
-                             "realtime_factor": round(args.track_seconds / best, 1),
-                             "segments": -(-(Lt + 22050 - 4033) // int(0.75 * N)),
+                             "realtime_factor": round(args.track_seconds / best, 1), "segments": nseg, "mode": "carry (the reference's)",
                              "includes": "pageable H2D of the track, all segments pipelined, overlap-add on device, D2H of 4 stems"}
             e1.close()
+            try:
+                lanes = max(2, min(64, nseg))
+                er = make_engine(lanes, False)
+                routs = [np.empty(2 * Lt, np.float32) for _ in range(4)]
+                er.separate_interleaved(ta, Lt, routs, flags=pkg.FLAG_RESET_SEGMENTS, shift_offset=4033)
+                best_r = min(er.separate_interleaved(ta, Lt, routs, flags=pkg.FLAG_RESET_SEGMENTS, shift_offset=4033) for _ in range(3))
+                sdr = [round(float(10 * np.log10(np.sum(touts[t].astype(np.float64) ** 2) /
+                                                 max(np.sum((touts[t].astype(np.float64) - routs[t]) ** 2), 1e-300))), 2) for t in range(4)]
+                line["track_reset_mode"] = {"wall_ms": round(best_r * 1e3, 2), "realtime_factor": round(args.track_seconds / best_r, 1),
+                                            "lanes": lanes, "passes": -(-nseg // lanes),
+                                            "sdr_db_vs_carry_per_stem": sdr,
+                                            "note": "opt-in deviation from umx.cpp:167-171,226-227 (zero LSTM state per segment); synthetic weights and "
+                                                    "audio: the SDR says how far the two modes are apart here, not what it is on music"}
+                er.close()
+            except Exception as e:  # noqa: BLE001
+                line["track_reset_mode"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -7,8 +7,8 @@ reference would use (fl(q*scale+offset), model.cpp:610-616):
   fc2 -> bn2 -> relu       K = 2048, u16 weights     [planes: two weight planes whose sum is the file's integer, 3 of the 4 plane products + the row-sum term]
   3-layer BiLSTM           2584-step-class recurrence, u8 W_hh, from the engine's fc1 output (torch float64 LSTM)
 for the GEMM flavours planes / bf16x3 (staged split), the single-track (VALU) and the batched (matrix-core) LSTM kernels, and the
-CPU oracle (fp32).  "32 lanes (shipped)" is the configuration the bench times: the launches are large enough for the 256 x 256
-ping-pong plane GEMM (csrc/gemm_planes_pp.h) and run the recurrence in workgroups of 8 lanes x 64 units (lstm_batch8_kernel, csrc/lstm_batch8.h);
+CPU oracle (fp32).  "64 lanes (shipped)" is the configuration the bench times: the launches are large enough for the persistent 256 x 256
+plane GEMM (csrc/gemm_planes_ps.h) and run the recurrence in workgroups of 8 lanes x 64 units, two octets in turn (lstm_batch8_kernel, csrc/lstm_batch8.h);
 the one- and two-lane rows run the 128 x 128 lock-step tiles and the same recurrence kernel (same arithmetic per element, tested bitwise).  (The fp32-MFMA flavour of rounds 1-2 is gone; its figures are in profiles/r02_accuracy_vs_float64.txt.)"""
 import sys
 import tempfile
@@ -22,7 +22,7 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as ge  # noqa: E402
 
 pkg, po = ge.load_package(), ge.load_oracle()
-H, N = 1024, 128 * 1024  # 32 lanes x 129 frames = 4128 rows: the 256 x 256 tiles
+H, N = 1024, 128 * 1024  # 64 lanes x 129 frames = 8256 rows: more 256 x 256 tiles than CUs in every GEMM
 d = tempfile.mkdtemp()
 path = f"{d}/m.bin"
 pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=7), H, compress=False)
@@ -46,7 +46,7 @@ def run(**kw):
 
 
 res = {"planes": run(gemm="planes"), "bf16x3": run(gemm="bf16x3"),
-       "planes+batched LSTM": run(gemm="planes", tracks=2), "32 lanes (shipped)": run(gemm="planes", tracks=32)}
+       "planes+batched LSTM": run(gemm="planes", tracks=2), "64 lanes (shipped)": run(gemm="planes", tracks=64)}
 oracle = {"fc1": taps["fc1_out"], "lstm": taps["lstm_out"], "fc2": taps["fc2_out"]}
 
 
@@ -84,7 +84,7 @@ for t in (0, 3):
     lstm.load_state_dict({f"{wn}_l{l}{sfx}": torch.from_numpy(g(t, f"lstm.{wn}_l{l}{sfx}").reshape(targets[t][f"lstm.{wn}_l{l}{sfx}"]["f32"].shape))
                           for l in range(3) for sfx in ("", "_reverse") for wn in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")})
     with torch.no_grad():
-        for name in ("planes", "planes+batched LSTM", "32 lanes (shipped)"):
+        for name in ("planes", "planes+batched LSTM", "64 lanes (shipped)"):
             want = lstm(torch.from_numpy(res[name]["fc1"][t].astype(np.float64))[:, None, :])[0][:, 0].numpy()
             report("lstm", name + (" (VALU kernel)" if name == "planes" else ""), res[name]["lstm"][t], want)
         want = lstm(torch.from_numpy(oracle["fc1"][t].astype(np.float64))[:, None, :])[0][:, 0].numpy()

@@ -92,7 +92,9 @@ template <bool INV> __device__ __forceinline__ void fft16(float2 (&v)[16])
 // Unscaled in both directions (dsp.cpp:136 Unscaled flag).
 // j: the thread's index inside the 256-thread group that owns buf (several groups of one workgroup may transform
 // side by side, each in its own buffer; the barriers are workgroup-wide, so every group must make the same calls).
-template <bool INV>
+// KEEP: leave the transform in registers instead -- v[q] = bin j + 256 q, the thread's own sixteen outputs of the last pass -- for a caller
+// whose next step is per element (the fused inverse STFT's weighting and overlap-add): no final store, no final barrier, no read back.
+template <bool INV, bool KEEP = false>
 __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const float2 *__restrict__ tw1,
                                         const float2 *__restrict__ tw2, int j)
 {
@@ -134,11 +136,13 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const floa
             v[r] = cmul_tw(v[r], INV ? cconj(w) : w);
         }
         fft16<INV>(v);
+        if (!KEEP)
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            buf[fft_pad(j + 256 * q)] = v[q];
+            for (int q = 0; q < 16; ++q)
+                buf[fft_pad(j + 256 * q)] = v[q];
     }
-    __syncthreads();
+    if (!KEEP)
+        __syncthreads();
 }
 
 template <bool INV>

@@ -45,6 +45,12 @@ constexpr unsigned PS_DROP = 0x40000000u; // an offset the rebased mask resource
 #ifndef PS_STORE_AUX
 #define PS_STORE_AUX 2
 #endif
+#ifndef PS_A_AUX
+#define PS_A_AUX 0 // cache policy of the staging loads of A / B (A/B builds)
+#endif
+#ifndef PS_B_AUX
+#define PS_B_AUX 0
+#endif
 #ifndef PS_PROFILE
 #define PS_PROFILE 0 // 1 (timing build): two workgroups print where the cycles of their tiles go
 #endif
@@ -128,12 +134,12 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         _Pragma("unroll") for (int it = 0; it < NA; ++it)                                                            \
         {                                                                                                            \
             const int so_ = ao_ + a_it[it];                                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(size_t)(lb_ + (it / PER) * A_PL + (it % PER) * DEAL * 1024), 16, voffA, so_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(size_t)(lb_ + (it / PER) * A_PL + (it % PER) * DEAL * 1024), 16, voffA, so_, 0, PS_A_AUX); \
         }                                                                                                            \
         _Pragma("unroll") for (int it = 0; it < NB; ++it)                                                            \
         {                                                                                                            \
             const int so_ = bo_ + b_it[it];                                                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(size_t)(lb_ + 2 * A_PL + (it / PER) * B_PL + (it % PER) * DEAL * 1024), 16, voffB, so_, 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(size_t)(lb_ + 2 * A_PL + (it / PER) * B_PL + (it % PER) * DEAL * 1024), 16, voffB, so_, 0, PS_B_AUX); \
         }                                                                                                            \
     }
 #define PS_DMA_ADVANCE()                                                                                             \

@@ -425,22 +425,14 @@ __device__ __forceinline__ void lstm8_body(const LstmBArgs &a, int chain, int sh
                     hlast[o] = h;
                     plast[o] = mine12;
                 }
-#ifndef LSTM8_STG_B32
-#define LSTM8_STG_B32 1
-#endif
-                if (LSTM8_STAGE_PLANES && have_planes && !LSTM8_STG_B32)
+                if (LSTM8_STAGE_PLANES && have_planes)
                 {
+                    // two bytes per lane and plane, rows of LSTM8_STG_PITCH ushorts: the eight tracks of a wave on eight bank quads.  (One
+                    // dword per pair of units from the even unit's lane -- half the lanes under an exec mask -- measured 2.5 % slower
+                    // per launch: profiles/r06_lstm8_staging_ab.txt.)
                     unsigned short *sg = stg + (o * 2 * 8 + tr) * LSTM8_STG_PITCH + w * 8 + tile * 4 + q;
                     sg[0] = (unsigned short)b1;
                     sg[8 * LSTM8_STG_PITCH] = (unsigned short)b2;
-                }
-                if (LSTM8_STAGE_PLANES && have_planes && LSTM8_STG_B32 && (q & 1) == 0)
-                {
-                    // the even unit of a pair stages both (it holds the odd unit's planes for the granule): one dword per plane, the 32
-                    // writing lanes of a wave on 32 different banks
-                    unsigned *sg = reinterpret_cast<unsigned *>(stg + (o * 2 * 8 + tr) * LSTM8_STG_PITCH + w * 8 + tile * 4 + q);
-                    sg[0] = b1 | (other12 << 16);
-                    sg[8 * LSTM8_STG_PITCH / 2] = b2 | (other12 & 0xffff0000u);
                 }
                 // the even unit of a pair publishes it (this unit, the next), tagged step + 1
                 granule_store16<FAST>(gran_rs[o], (lane_on[o] && (q & 1) == 0) ? (step & 1) * gslot + pub_off : LSTM8_OOR,

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     for (int r = 0; r < 16; ++r)
         v[r] = buf[fft_pad(j + 256 * r)];
     __syncthreads();
-    fft4096<true>(v, buf, tw1, tw2, j);
+    fft4096<true, true>(v, buf, tw1, tw2, j); // (the result stays in v: sample j + 256 r = v[r])
     if (WI_PROFILE)
         c3 = clock64();
     // ---- the frame's weighted samples: overlap-added on the way out.  Hop block h = samples [h HOP, (h + 1) HOP) of the
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     for (int r = 0; r < 16; ++r)
     {
         const int i = j + 256 * r;
-        const float2 z = buf[fft_pad(i)];
+        const float2 z = v[r];
         const float w = window[i];
         const float den = nw[start + i] + 1e-8f;
         // dsp.cpp:248-256: frame * w * 1.0f / 4096 / (nw + 1e-8f), in that order.  The division by 4096 is an exact scaling; the one
