@@ -10,9 +10,10 @@
 //   * the staging stream runs ahead across tile boundaries: when the last trip of a tile is multiplied the first stages of the next
 //     tile are already in LDS (ONE tile cursor, decoded STAGES - 1 trips ahead by the staging side and handed on to the multiplying
 //     side; the per-piece staging offsets are rebuilt at a tile switch, a trip adds 64 bytes);
-//   * stores are fire and forget: nothing waits for their acknowledgement but the in-order memory counter, and the waits of the two
-//     trips behind an epilogue are relaxed to "all but the 63 youngest operations" (the 128 stores are younger than every stage
-//     those waits are about);
+//   * stores are fire and forget: every stage in flight is waited for right BEFORE the epilogue's stores go out, so the waits of the
+//     two trips behind it are about stages that have landed already and wait for nothing -- the in-order memory counter would
+//     otherwise make them count store acknowledgements (the first form relaxed them to "all but the 63 youngest operations", which
+//     still waits for 65 acknowledgements: fc3 +2.5 %, -DPS_PREWAIT=0);
 //   * the accumulators are the only copy of a tile's result, so its epilogue must be ISSUED before the next tile's first matrix
 //     instruction overwrites them -- but not a cycle earlier: trip 0 of a tile handles band mi = 0 .. 3 as { fix-up, bn / bias /
 //     activation and stores of the previous tile's band ; the band's matrix instructions of the first 16-k step, starting from a zero
@@ -44,6 +45,9 @@ constexpr unsigned PS_DROP = 0x40000000u; // an offset the rebased mask resource
 // L2s.  W_ih 9.65 -> 8.9 ms per launch, fc3 13.7 -> 13.4 (profiles/r06_ps_store_policy.txt; 0 = default policy, 16 = sc1: no change).
 #ifndef PS_STORE_AUX
 #define PS_STORE_AUX 2
+#endif
+#ifndef PS_PREWAIT
+#define PS_PREWAIT 1 // 1: every stage in flight is waited for BEFORE the epilogue's stores go out, so that no later wait has to count acknowledgements of stores (0: vmcnt(63) behind them)
 #endif
 #ifndef PS_A_AUX
 #define PS_A_AUX 0 // cache policy of the staging loads of A / B (A/B builds)
@@ -389,7 +393,7 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
 
     // ---- the phases of a trip.  M: staging of trip u + STAGES - 1, the fragments of this trip (FIRST trip of a tile: of its first
     // 16-k step only).  LATE: group 0 stages at the start of its C phase (kt = 1: group 1 is still reading trip u - 1's stage).
-    // YOUNG: at least 64 stores are younger than every stage the wait is about (the trips behind an epilogue).
+    // YOUNG: the wait of a trip behind an epilogue -- about a stage that landed before the epilogue's stores were issued (PS_PREWAIT).
     int cur = 0, u = 0;
 #define PS_M(FIRST, LATE, YOUNG1, TAB, FINISH, SPLIT)                                                                       \
     {                                                                                                                \
@@ -413,7 +417,10 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         {                                                                                                            \
             /* group 1's half of trip u + 1 has landed; the pieces of trip u + 2 it has just issued may stay in flight */ \
             if (YOUNG1)                                                                                              \
-                PS_WAIT_VM(63);                                                                                      \
+            {                                                                                                        \
+                if (!PS_PREWAIT)                                                                                     \
+                    PS_WAIT_VM(63);                                                                                  \
+            }                                                                                                        \
             else if (u + 2 < ntrips)                                                                                 \
                 PS_WAIT_VM(DMA_PER_WAVE);                                                                            \
             else                                                                                                     \
@@ -433,7 +440,10 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
         if (grp == 0 && u + 1 < ntrips)                                                                              \
         {                                                                                                            \
             if (YOUNG0)                                                                                              \
-                PS_WAIT_VM(63);                                                                                      \
+            {                                                                                                        \
+                if (!PS_PREWAIT)                                                                                     \
+                    PS_WAIT_VM(63);                                                                                  \
+            }                                                                                                        \
             else if (STAGES == 3 && u + 2 < ntrips)                                                                  \
                 PS_WAIT_VM(DMA_PER_WAVE);                                                                            \
             else                                                                                                     \
@@ -525,6 +535,8 @@ template <int MODE, int NBP> __global__ __launch_bounds__(512, 1) void gemm_plan
                 pq_t2 = clock64();
                 pq_epi_m += pq_t2 - pq_t1;
             }
+            if (PS_PREWAIT && issuer)
+                PS_WAIT_VM(0); // the stages of trips u + 1 (and u + 2) have landed: the waits of the next two trips are about nothing younger
             PS_EPI_SETUP()
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
