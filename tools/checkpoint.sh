@@ -12,5 +12,7 @@ grep -E "passed|failed" gpurun_out/$tag/pytest_gpu.log | tail -2
 bash tools/profile_round.sh $tag 2>&1 | tail -2
 bash tools/pmc_gemm.sh --tracks 64 > gpurun_out/$tag/pmc_sq_counters.txt 2>&1
 timeout 900 python tools/gemm_accuracy.py > gpurun_out/$tag/accuracy_vs_float64.txt 2>&1
+# in-kernel tile profile of the persistent GEMM (timing build variants/libumx_hip_psprof.so = -DPS_PROFILE=1, if it was built)
+if [ -f variants/libumx_hip_psprof.so ]; then UMX_HIP_LIB=$PWD/variants/libumx_hip_psprof.so python tools/which_gemm.py 64 2>&1 | grep -E "# ps" | sort > gpurun_out/$tag/ps_tile_profile_raw.txt; fi
 tail -30 gpurun_out/$tag/accuracy_vs_float64.txt
 python tools/bench_brief.py gpurun_out/prof_$tag/bench.json | head -12
