@@ -3,10 +3,10 @@
 # track / reset-mode legs and the CPU baseline), rocprofv3 kernel stats + FETCH / WRITE of the same command, SQ counters of the GEMM /
 # recurrence / split kernels at the bench's lane count, accuracy table against float64; ~20 GPU-minutes.  Copy what is to be judged from
 # gpurun_out/<tag>/ and gpurun_out/prof_<tag>/ into profiles/.
-tag=${1:-r06_final}
+tag=${1:-r06_v1}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$tag
-git rev-parse HEAD > gpurun_out/$tag/head.txt 2>/dev/null
+echo ${HEAD_SHA:-unknown} > gpurun_out/$tag/head.txt # (the snapshot on the GPU box has no .git: HEAD_SHA=$(git rev-parse HEAD) gpurun -- 'HEAD_SHA=... bash tools/checkpoint.sh')
 timeout 1700 python -m pytest tests -m gpu -q > gpurun_out/$tag/pytest_gpu.log 2>&1
 grep -E "passed|failed" gpurun_out/$tag/pytest_gpu.log | tail -2
 bash tools/profile_round.sh $tag 2>&1 | tail -2
