@@ -176,6 +176,32 @@ def test_persistent_gemm_gives_the_bits_of_the_ping_pong_kernel(pkg, tmp_path, m
             assert (res[ps][1][b] == res["15"][1][b]).all(), (ps, b)
 
 
+@pytest.mark.parametrize("flags", [0x700, 0x300, 0x1], ids=["vocals_only", "two_targets", "no_wiener"])
+def test_persistent_gemm_with_skipped_targets(pkg, tmp_path, monkeypatch, flags):
+    """The persistent walk is flattened over the ACTIVE targets (BASELINE config 1 skips three, umx_hip.h UMX_FLAG_SKIP_TARGET): one,
+    two and four targets in the tile list must give the ping-pong kernel's bits (stems of every lane, carried state)."""
+    H, N, B = 512, 900 * 1024, 16
+    path = str(tmp_path / "m.bin")
+    pkg.ggml.write_model(path, pkg.ggml.synth_weights(H, seed=59), H, compress=False)
+    waves = [pkg.ggml.synth_audio(N - 211 * b, 1700 + b) for b in range(B)]
+    res = {}
+    for ps in ("0", None):
+        if ps is None:
+            monkeypatch.delenv("UMX_GEMM_PS", raising=False)
+        else:
+            monkeypatch.setenv("UMX_GEMM_PS", ps)
+        eng = pkg.Engine.from_file(path, N, tracks=B, quantised=True)
+        outs = eng.infer_batch(waves, flags)
+        names = [eng.gemm_kernel_name(m) for m in range(4)]  # (fc1 / fc2 of ONE target have fewer 256 x 256 tiles than CUs: the 128 x 128 kernel)
+        assert all(names[m] == ("gemm_planes_ps_kernel" if ps is None else "gemm_planes_pp_kernel") for m in (1, 3)), (ps, names)
+        res[ps] = (outs, [eng.track_stream_get(b) for b in range(B)])
+        eng.close()
+    for b in range(B):
+        assert (res[None][1][b] == res["0"][1][b]).all(), b
+        for t in range(4):
+            assert (res[None][0][b][t] == res["0"][0][b][t]).all(), (b, t)
+
+
 def test_groups_of_16_lanes_one_launch_after_the_other_give_a_lane_its_bits(pkg, tmp_path, monkeypatch):
     """Contexts that csrc/lstm_batch8.h does not take -- hidden 256 / 128, fp32-resident W_hh, or UMX_LSTM8_MIN_LANES=99 -- run
     lstm_batch_kernel, one group of 16 lanes per launch, the groups of a larger context one after the other (round 6: the side-by-side,
