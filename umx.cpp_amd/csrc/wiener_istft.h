@@ -39,6 +39,28 @@ __device__ __forceinline__ float2 ld_stream(const float2 *p)
 }
 __device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
 
+typedef unsigned wi_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned wi_u4 __attribute__((ext_vector_type(4)));
+template <int AUX> __device__ __forceinline__ float2 bld2(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const wi_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, AUX);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+template <int AUX> __device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, AUX));
+}
+template <int AUX> __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t rs, int voff, int soff)
+{
+    const wi_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void bst2(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float2 v)
+{
+    const wi_u2 t = {__float_as_uint(v.x), __float_as_uint(v.y)};
+    __builtin_amdgcn_raw_buffer_store_b64(t, rs, voff, soff, 0);
+}
+
 template <bool WIENER>
 __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__restrict__ spec, WienerMags mags, int T,
                                                                   const unsigned *__restrict__ maxabs_bits,
@@ -64,11 +86,24 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     }
     constexpr int src0 = 0;
     const int tid = threadIdx.x;
+    // Every streamed access goes through a buffer resource with a scalar base and 32-bit offsets (round 6): a uniform part in an SGPR
+    // (frame, channel, source), the thread's part in ONE register per phase -- the 64-bit address arithmetic of a dozen global loads and
+    // stores per bin and sample was 9 % of the vector instructions of a kernel that is bound by them.  aux 2 = non-temporal: the inputs
+    // are read once (they would push the stems' lines out of the L2).
+    const __amdgpu_buffer_rsrc_t rs_spec = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(spec), 0, (int)((size_t)2 * T * NBINS * 8), 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_mag[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        rs_mag[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(mags.m[s]), 0, (int)((size_t)2 * T * MAGP * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Rc), 0, (int)((size_t)4 * NBINS * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(window), 0, NFFT * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_nw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nw), 0, (int)(((size_t)(T - 1) * HOP + NFFT) * 4), 0x00020000);
     const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;
     const int f0 = (int)blockIdx.x * run_len, f1 = min(T, f0 + run_len);
-    const int g = tid >> 8; // source (of this workgroup's); j = tid & 255: thread of its transform
+    const int g = __builtin_amdgcn_readfirstlane(tid >> 8); // source (of this workgroup's: four waves each); j = tid & 255: thread of its transform
     float2 *const stem = reinterpret_cast<float2 *>(out.p[blockIdx.z][src0 + g]);
     const int n_out = out.n[blockIdx.z];
+    const __amdgpu_buffer_rsrc_t rs_stem = __builtin_amdgcn_make_buffer_rsrc(stem, 0, n_out * 8, 0x00020000);
     [[maybe_unused]] long long pf[5] = {0, 0, 0, 0, 0};
     float2 open[3][4]; // the open hop blocks' sums at this thread's positions (see the overlap-add below)
 #pragma unroll
@@ -95,14 +130,13 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
 #pragma unroll
     for (int q = 0; q < 2; ++q)
     {
-        const int b = tl + WI_THREADS * q;
-        Xq[q][0] = ld_stream(spec + ((size_t)0 * T + f) * NBINS + b);
-        Xq[q][1] = ld_stream(spec + ((size_t)1 * T + f) * NBINS + b);
+        Xq[q][0] = bld2<2>(rs_spec, tl * 8, ((0 * T + f) * NBINS + WI_THREADS * q) * 8);
+        Xq[q][1] = bld2<2>(rs_spec, tl * 8, ((1 * T + f) * NBINS + WI_THREADS * q) * 8);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            mq[q][0][s] = ld_stream(mags.m[s] + mask_index(0, T, f, b));
-            mq[q][1][s] = ld_stream(mags.m[s] + mask_index(1, T, f, b));
+            mq[q][0][s] = bld1<2>(rs_mag[s], tl * 4, ((0 * T + f) * MAGP + WI_THREADS * q) * 4); // mask_index(c, T, f, b)
+            mq[q][1][s] = bld1<2>(rs_mag[s], tl * 4, ((1 * T + f) * MAGP + WI_THREADS * q) * 4);
         }
     }
 #pragma unroll
@@ -126,13 +160,13 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
         }
         else
         {
-            X0 = ld_stream(spec + ((size_t)0 * T + f) * NBINS + b);
-            X1 = ld_stream(spec + ((size_t)1 * T + f) * NBINS + b);
+            X0 = bld2<2>(rs_spec, tl * 8, ((0 * T + f) * NBINS + WI_THREADS * q) * 8);
+            X1 = bld2<2>(rs_spec, tl * 8, ((1 * T + f) * NBINS + WI_THREADS * q) * 8);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
             {
-                m0[s] = ld_stream(mags.m[s] + mask_index(0, T, f, b));
-                m1[s] = ld_stream(mags.m[s] + mask_index(1, T, f, b));
+                m0[s] = bld1<2>(rs_mag[s], tl * 4, ((0 * T + f) * MAGP + WI_THREADS * q) * 4);
+                m1[s] = bld1<2>(rs_mag[s], tl * 4, ((1 * T + f) * MAGP + WI_THREADS * q) * 4);
             }
         }
         const float h0 = mix_magnitude(X0), h1 = mix_magnitude(X1);
@@ -149,7 +183,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
         {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                rc[s] = *reinterpret_cast<const float4 *>(Rc + ((size_t)s * NBINS + b) * 4);
+                rc[s] = bld4<0>(rs_rc, tl * 16, (s * NBINS + WI_THREADS * q) * 16); // (R is L2-resident and re-read by every frame: default policy)
             wiener_bin_setup(X0, X1, m0, m1, rc, max_abs, rmax, wb);
         }
         else
@@ -212,15 +246,15 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     // frames, whose terms come first: the run's first three frames are kept in `frames` and wiener_ola_edges_kernel adds their
     // chunks to those blocks afterwards, in order, on top of what the previous run flushed at its end (below the loop).
     float2 *dst = frames + ((size_t)(src0 + g) * T + f) * NFFT;
-    const size_t start = (size_t)f * HOP;
+    const int start = f * HOP;
     const bool keep = f - f0 < 3; // one of the run's first three frames
 #pragma unroll
     for (int r = 0; r < 16; ++r)
     {
         const int i = j + 256 * r;
         const float2 z = v[r];
-        const float w = window[i];
-        const float den = nw[start + i] + 1e-8f;
+        const float w = bld1<0>(rs_win, j * 4, r * 1024);
+        const float den = bld1<0>(rs_nw, j * 4, (start + 256 * r) * 4) + 1e-8f;
         // dsp.cpp:248-256: frame * w * 1.0f / 4096 / (nw + 1e-8f), in that order.  The division by 4096 is an exact scaling; the one
         // by den (shared by both channels) as reciprocal + exact-remainder correction (div_by, common.h: the correctly rounded
         // quotient, the bits of the IEEE division istft_frames_kernel performs -- the fused-vs-unfused test compares them):
@@ -235,9 +269,9 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
         if (c == 0)
         {
             // block f is complete
-            const int s_out = (int)start + i - NFFT / 2;
-            if (f >= f0 + 3 && s_out >= 0 && s_out < n_out)
-                stem[s_out] = sum;
+            // (sample start + i - 2048 of the stem: negative or >= n_out = out of the resource's range, the store is dropped)
+            if (f >= f0 + 3)
+                bst2(rs_stem, j * 8, (start + 256 * r - NFFT / 2) * 8, sum);
         }
         else
             open[c - 1][q] = sum; // block f + c = block (f + 1) + (c - 1)
