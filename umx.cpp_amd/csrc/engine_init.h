@@ -823,7 +823,7 @@ int umx_hip_ctx::init(int device_, int hidden, int segment_samples, const umx_te
         for (const void *fn : bxs)
             UMX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, BX_LDS_BYTES));
         {
-            const int wi_lds = 4 * FFT_LDS_ELEMS * (int)sizeof(float2); // 139,264 (NSRC = 4; 2 and 1 need less)
+            const int wi_lds = (int)WI_LDS_BYTES; // 155,648: four transforms + the window
             UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
             UMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(wiener_istft_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, wi_lds));
         }

@@ -409,10 +409,10 @@ int umx_hip_ctx::stage_finish(Slot &sl, hipStream_t st, int nb, const float *con
         // one 1024-thread workgroup per run, all four sources (two / one source per workgroup, i.e. more workgroups per CU that
         // each repeat the source-independent part, measured 1.7x / 2.7x slower in round 2)
         if (flags & UMX_FLAG_NO_WIENER)
-            hipLaunchKernelGGL((wiener_istft_kernel<false>), dim3(nruns, 1, lanes.count), dim3(1024), (size_t)4 * FFT_LDS_ELEMS * sizeof(float2), st, L0.spec, wm0,
+            hipLaunchKernelGGL((wiener_istft_kernel<false>), dim3(nruns, 1, lanes.count), dim3(1024), WI_LDS_BYTES, st, L0.spec, wm0,
                                T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, ls, run_len, oo);
         else
-            hipLaunchKernelGGL((wiener_istft_kernel<true>), dim3(nruns, 1, lanes.count), dim3(1024), (size_t)4 * FFT_LDS_ELEMS * sizeof(float2), st, L0.spec, wm0,
+            hipLaunchKernelGGL((wiener_istft_kernel<true>), dim3(nruns, 1, lanes.count), dim3(1024), WI_LDS_BYTES, st, L0.spec, wm0,
                                T, L0.maxabs, L0.Rc, window, nw, tw1, tw2, L0.frames, ydbg, ls, run_len, oo);
         stage_range(ST_OLA);
         UMX_HIP_CHECK(hipEventRecord(sl.ev[ST_OLA], st));

@@ -28,6 +28,9 @@
 namespace umx
 {
 
+// dynamic LDS of wiener_istft_kernel: the four transforms' buffers + the synthesis window (16 KB) + one hop of the window sum-square (4 KB): 159,744 B
+constexpr size_t WI_LDS_BYTES = (size_t)4 * FFT_LDS_ELEMS * sizeof(float2) + NFFT * sizeof(float) + HOP * sizeof(float);
+
 // (Two or one source per workgroup -- 2 / 4 workgroups per frame, each repeating phase 1's source-independent part, in exchange for
 // more workgroups per CU whose phases overlap -- measured 1.7x / 2.7x slower in round 2; the template parameter is gone.)
 // streamed-once inputs: non-temporal loads, so that they do not push the stems' read-modify-write lines out of the L2
@@ -69,7 +72,9 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
                                                                   const float2 *__restrict__ tw2, float2 *__restrict__ frames,
                                                                   float2 *__restrict__ y_dbg, WienerStrides ls, int run_len, OlaOut out)
 {
-    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [4 sources][FFT_LDS_ELEMS]
+    extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [4 sources][FFT_LDS_ELEMS], then the window [NFFT], then nw of an interior hop block [HOP]
+    float *const wi_win = reinterpret_cast<float *>(wi_buf + 4 * FFT_LDS_ELEMS);
+    float *const wi_nwp = wi_win + NFFT;
     constexpr int NSRC = 4, WI_THREADS = 256 * NSRC;
     const LaneSet &lanes = out.lanes;
     {
@@ -86,6 +91,12 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     }
     constexpr int src0 = 0;
     const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        wi_win[tid + 1024 * r] = window[tid + 1024 * r]; // (visible after the first frame's barriers)
+    // A hop block all four of whose frames exist (3 <= h <= T - 1) has the SAME window sum-square as every other such block: the host adds
+    // w^2 of chunks 3, 2, 1, 0 in that order (engine_init.h) -- block 3 stands for them all (in range for every T: the array ends at block T + 2)
+    wi_nwp[tid] = nw[3 * HOP + tid];
     // Every streamed access goes through a buffer resource with a scalar base and 32-bit offsets (round 6): a uniform part in an SGPR
     // (frame, channel, source), the thread's part in ONE register per phase -- the 64-bit address arithmetic of a dozen global loads and
     // stores per bin and sample was 9 % of the vector instructions of a kernel that is bound by them.  aux 2 = non-temporal: the inputs
@@ -96,7 +107,6 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     for (int s = 0; s < 4; ++s)
         rs_mag[s] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(mags.m[s]), 0, (int)((size_t)2 * T * MAGP * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Rc), 0, (int)((size_t)4 * NBINS * 16), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(window), 0, NFFT * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_nw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(nw), 0, (int)(((size_t)(T - 1) * HOP + NFFT) * 4), 0x00020000);
     const float max_abs = WIENER ? wiener_max_abs(maxabs_bits) : 1.0f, rmax = 1.0f / max_abs;
     const int f0 = (int)blockIdx.x * run_len, f1 = min(T, f0 + run_len);
@@ -111,6 +121,24 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             open[c][q] = make_float2(0.f, 0.f);
+    float2 Xq[2][2]; // the mixture and the four masks of the thread's two main bins: 24 registers that ride from one frame's overlap-add to the next frame's gains
+    float mq[2][2][4];
+#define WI_REQUEST(f_, tl_, q_)                                                                                                        \
+    {                                                                                                                                  \
+        Xq[q_][0] = bld2<2>(rs_spec, (tl_) * 8, ((0 * T + (f_)) * NBINS + WI_THREADS * (q_)) * 8);                                      \
+        Xq[q_][1] = bld2<2>(rs_spec, (tl_) * 8, ((1 * T + (f_)) * NBINS + WI_THREADS * (q_)) * 8);                                      \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                                  \
+        {                                                                                                                              \
+            mq[q_][0][s] = bld1<2>(rs_mag[s], (tl_) * 4, ((0 * T + (f_)) * MAGP + WI_THREADS * (q_)) * 4); /* mask_index(c, T, f, b) */ \
+            mq[q_][1][s] = bld1<2>(rs_mag[s], (tl_) * 4, ((1 * T + (f_)) * MAGP + WI_THREADS * (q_)) * 4);                              \
+        }                                                                                                                              \
+    }
+    if (f0 < f1)
+    {
+        int tl0 = tid;
+        asm volatile("" : "+v"(tl0));
+        WI_REQUEST(f0, tl0, 0);
+    }
     for (int f = f0; f < f1; ++f)
     {
     [[maybe_unused]] long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
@@ -121,24 +149,12 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     int tl = tid;
     asm volatile("" : "+v"(tl));
     const int j = tl & 255;
-    // the streamed inputs (mixture, masks: HBM) of BOTH main bins of the thread are requested before the first is used -- round 3
-    // requested a bin's fourteen loads, waited for them, computed, and only then requested the next bin's: two memory latencies
-    // per frame with every wave of the workgroup in the same place.  (R is L2-resident and stays with its bin: 16 registers.)
+    // The streamed inputs (mixture, masks: HBM) of the thread's FIRST bin were requested during the previous frame's overlap-add (WI_REQUEST below;
+    // the run's first frame in front of the loop) and those of its second bin are requested here, a bin's arithmetic ahead of their use: no
+    // memory latency at the top of a frame with every wave of the workgroup in the same place (rounds 4-5 requested both bins here and waited;
+    // both bins during the overlap-add: 24 registers more than that phase has).  (R is L2-resident and stays with its bin: 16 registers.)
+    WI_REQUEST(f, tl, 1);
     constexpr int NQ = (NFFT / 2 + WI_THREADS) / WI_THREADS; // 3: bins tl, tl + 1024, and 2048 for thread 0
-    float2 Xq[2][2];
-    float mq[2][2][4];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-    {
-        Xq[q][0] = bld2<2>(rs_spec, tl * 8, ((0 * T + f) * NBINS + WI_THREADS * q) * 8);
-        Xq[q][1] = bld2<2>(rs_spec, tl * 8, ((1 * T + f) * NBINS + WI_THREADS * q) * 8);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-        {
-            mq[q][0][s] = bld1<2>(rs_mag[s], tl * 4, ((0 * T + f) * MAGP + WI_THREADS * q) * 4); // mask_index(c, T, f, b)
-            mq[q][1][s] = bld1<2>(rs_mag[s], tl * 4, ((1 * T + f) * MAGP + WI_THREADS * q) * 4);
-        }
-    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
     {
@@ -248,34 +264,65 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     float2 *dst = frames + ((size_t)(src0 + g) * T + f) * NFFT;
     const int start = f * HOP;
     const bool keep = f - f0 < 3; // one of the run's first three frames
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-    {
-        const int i = j + 256 * r;
-        const float2 z = v[r];
-        const float w = bld1<0>(rs_win, j * 4, r * 1024);
-        const float den = bld1<0>(rs_nw, j * 4, (start + 256 * r) * 4) + 1e-8f;
-        // dsp.cpp:248-256: frame * w * 1.0f / 4096 / (nw + 1e-8f), in that order.  The division by 4096 is an exact scaling; the one
-        // by den (shared by both channels) as reciprocal + exact-remainder correction (div_by, common.h: the correctly rounded
-        // quotient, the bits of the IEEE division istft_frames_kernel performs -- the fused-vs-unfused test compares them):
-        // 7 instead of 22 instructions per sample in a kernel that is bound by its VALU instructions (WI_PROFILE)
-        const float rden = __builtin_amdgcn_rcpf(den);
-        const float2 val = make_float2(div_by(z.x * w * 1.0f / float(NFFT), den, rden), div_by(z.y * w * 1.0f / float(NFFT), den, rden));
-        if (keep)
-            dst[i] = val;
-        const int c = r >> 2, q = r & 3;
-        const float2 a = c < 3 ? open[c < 3 ? c : 0][q] : make_float2(0.f, 0.f);
-        const float2 sum = make_float2(a.x + val.x, a.y + val.y);
-        if (c == 0)
+    // The NEXT frame's inputs are requested here, to arrive under this phase and the barrier.  Vector memory returns in order: whatever this phase
+    // loaded behind the request would wait for it -- so an INTERIOR frame (hop blocks f .. f + 3 complete: all but the first and last three of
+    // a segment) takes window and normalisation from LDS (four values of nw per thread: it repeats with the hop) and requests first; an edge
+    // frame reads nw from memory as before and requests last.
+    const bool interior = f >= 3 && f + 3 <= T - 1;
+    auto overlap_add = [&](auto in_c) {
+        constexpr bool IN = decltype(in_c)::value;
+        float d4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (IN)
         {
-            // block f is complete
-            // (sample start + i - 2048 of the stem: negative or >= n_out = out of the resource's range, the store is dropped)
-            if (f >= f0 + 3)
-                bst2(rs_stem, j * 8, (start + 256 * r - NFFT / 2) * 8, sum);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+            {
+                d4[q] = wi_nwp[j + 256 * q] + 1e-8f;
+                r4[q] = __builtin_amdgcn_rcpf(d4[q]);
+            }
+            if (f + 1 < f1)
+            {
+                WI_REQUEST(f + 1, tl, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        else
-            open[c - 1][q] = sum; // block f + c = block (f + 1) + (c - 1)
-    }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+            const int i = j + 256 * r;
+            const float2 z = v[r];
+            const float w = wi_win[i];
+            const float den = IN ? d4[r & 3] : bld1<0>(rs_nw, j * 4, (start + 256 * r) * 4) + 1e-8f;
+            // dsp.cpp:248-256: frame * w * 1.0f / 4096 / (nw + 1e-8f), in that order.  The division by 4096 is an exact scaling; the one
+            // by den (shared by both channels) as reciprocal + exact-remainder correction (div_by, common.h: the correctly rounded
+            // quotient, the bits of the IEEE division istft_frames_kernel performs -- the fused-vs-unfused test compares them):
+            // 7 instead of 22 instructions per sample in a kernel that is bound by its VALU instructions (WI_PROFILE)
+            const float rden = IN ? r4[r & 3] : __builtin_amdgcn_rcpf(den);
+            const float2 val = make_float2(div_by(z.x * w * 1.0f / float(NFFT), den, rden), div_by(z.y * w * 1.0f / float(NFFT), den, rden));
+            if (keep)
+                dst[i] = val;
+            const int c = r >> 2, q = r & 3;
+            const float2 a = c < 3 ? open[c < 3 ? c : 0][q] : make_float2(0.f, 0.f);
+            const float2 sum = make_float2(a.x + val.x, a.y + val.y);
+            if (c == 0)
+            {
+                // block f is complete
+                // (sample start + i - 2048 of the stem: negative or >= n_out = out of the resource's range, the store is dropped)
+                if (f >= f0 + 3)
+                    bst2(rs_stem, j * 8, (start + 256 * r - NFFT / 2) * 8, sum);
+            }
+            else
+                open[c - 1][q] = sum; // block f + c = block (f + 1) + (c - 1)
+        }
+        if (!IN && f + 1 < f1)
+        {
+            WI_REQUEST(f + 1, tl, 0);
+        }
+    };
+    if (interior)
+        overlap_add(std::true_type{});
+    else
+        overlap_add(std::false_type{});
     // the transforms' buffers are free for the next frame's gains: an LDS-only barrier -- __syncthreads() would also wait for the
     // acknowledgements of this frame's stores (vmcnt(0)) with every wave idle, and nothing reads them back
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -302,6 +349,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
                     stem[s_out] = open[c][q];
             }
     }
+#undef WI_REQUEST
     if (WI_PROFILE && blockIdx.x == 7 && blockIdx.z == 3 && (tid == 0 || tid == 777))
         printf("# wiener_istft thread %d, %d frames: cycles per frame  loads+gains %lld  barrier %lld  transform %lld  weight+overlap-add+drain %lld\n", tid,
                f1 - f0, pf[0] / (f1 - f0), pf[1] / (f1 - f0), pf[2] / (f1 - f0), pf[3] / (f1 - f0));
