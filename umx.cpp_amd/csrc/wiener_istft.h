@@ -28,8 +28,8 @@
 namespace umx
 {
 
-// dynamic LDS of wiener_istft_kernel: the four transforms' buffers + the synthesis window (16 KB) + one hop of the window sum-square (4 KB): 159,744 B
-constexpr size_t WI_LDS_BYTES = (size_t)4 * FFT_LDS_ELEMS * sizeof(float2) + NFFT * sizeof(float) + HOP * sizeof(float);
+// dynamic LDS of wiener_istft_kernel: the four transforms' buffers + the synthesis window (16 KB) + one hop of the window sum-square (4 KB) + the second pass's twiddles (2 KB): 161,792 of 163,840 B
+constexpr size_t WI_LDS_BYTES = (size_t)4 * FFT_LDS_ELEMS * sizeof(float2) + NFFT * sizeof(float) + HOP * sizeof(float) + 256 * sizeof(float2);
 
 // (Two or one source per workgroup -- 2 / 4 workgroups per frame, each repeating phase 1's source-independent part, in exchange for
 // more workgroups per CU whose phases overlap -- measured 1.7x / 2.7x slower in round 2; the template parameter is gone.)
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     extern __shared__ __attribute__((aligned(16))) float2 wi_buf[]; // [4 sources][FFT_LDS_ELEMS], then the window [NFFT], then nw of an interior hop block [HOP]
     float *const wi_win = reinterpret_cast<float *>(wi_buf + 4 * FFT_LDS_ELEMS);
     float *const wi_nwp = wi_win + NFFT;
+    float2 *const wi_tw1 = reinterpret_cast<float2 *>(wi_nwp + HOP); // tw1: 15 instead of 30 twiddle loads per thread and frame through the CU's one vector-memory path
     constexpr int NSRC = 4, WI_THREADS = 256 * NSRC;
     const LaneSet &lanes = out.lanes;
     {
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     // A hop block all four of whose frames exist (3 <= h <= T - 1) has the SAME window sum-square as every other such block: the host adds
     // w^2 of chunks 3, 2, 1, 0 in that order (engine_init.h) -- block 3 stands for them all (in range for every T: the array ends at block T + 2)
     wi_nwp[tid] = nw[3 * HOP + tid];
+    if (tid < 256)
+        wi_tw1[tid] = tw1[tid];
     // Every streamed access goes through a buffer resource with a scalar base and 32-bit offsets (round 6): a uniform part in an SGPR
     // (frame, channel, source), the thread's part in ONE register per phase -- the 64-bit address arithmetic of a dozen global loads and
     // stores per bin and sample was 9 % of the vector instructions of a kernel that is bound by them.  aux 2 = non-temporal: the inputs
@@ -153,6 +156,15 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     // the run's first frame in front of the loop) and those of its second bin are requested here, a bin's arithmetic ahead of their use: no
     // memory latency at the top of a frame with every wave of the workgroup in the same place (rounds 4-5 requested both bins here and waited;
     // both bins during the overlap-add: 24 registers more than that phase has).  (R is L2-resident and stays with its bin: 16 registers.)
+    // (R of the first bin goes out in front of that request: it is what the bin waits for next, and vector memory returns in order)
+    float4 rc0[4];
+    if (WIENER)
+    {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            rc0[s] = bld4<0>(rs_rc, tl * 16, (s * NBINS) * 16); // (R is L2-resident and re-read by every frame: default policy)
+        __builtin_amdgcn_sched_barrier(0);
+    }
     WI_REQUEST(f, tl, 1);
     constexpr int NQ = (NFFT / 2 + WI_THREADS) / WI_THREADS; // 3: bins tl, tl + 1024, and 2048 for thread 0
 #pragma unroll
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
         {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                rc[s] = bld4<0>(rs_rc, tl * 16, (s * NBINS + WI_THREADS * q) * 16); // (R is L2-resident and re-read by every frame: default policy)
+                rc[s] = q == 0 ? rc0[s] : bld4<0>(rs_rc, tl * 16, (s * NBINS + WI_THREADS * q) * 16);
             wiener_bin_setup(X0, X1, m0, m1, rc, max_abs, rmax, wb);
         }
         else
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(1024) void wiener_istft_kernel(const float2 *__rest
     for (int r = 0; r < 16; ++r)
         v[r] = buf[fft_pad(j + 256 * r)];
     __syncthreads();
-    fft4096<true, true>(v, buf, tw1, tw2, j); // (the result stays in v: sample j + 256 r = v[r])
+    fft4096<true, true>(v, buf, wi_tw1, tw2, j); // (the result stays in v: sample j + 256 r = v[r])
     if (WI_PROFILE)
         c3 = clock64();
     // ---- the frame's weighted samples: overlap-added on the way out.  Hop block h = samples [h HOP, (h + 1) HOP) of the
