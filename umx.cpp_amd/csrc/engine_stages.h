@@ -292,7 +292,7 @@ int umx_hip_ctx::stage_front(Slot &sl, hipStream_t st, int nb, const float *cons
         }
         Lane &L0 = sl.lane[0];
         UMX_HIP_CHECK(hipMemsetAsync(L0.maxabs, 0, sizeof(unsigned) * B, st)); // per-call scratch of every lane
-        hipLaunchKernelGGL(stft_kernel, dim3(T, in.lanes.count), dim3(256), 0, st, in, N, T, window, tw1, tw2, L0.spec, lane_strides().spec, L0.x,
+        hipLaunchKernelGGL(stft_kernel, dim3((T + STFT_RUN - 1) / STFT_RUN, in.lanes.count), dim3(256), 0, st, in, N, T, window, tw1, tw2, L0.spec, lane_strides().spec, L0.x,
                            (size_t)Tp * KX, L0.maxabs);
     }
     stage_range(ST_FC1);
