@@ -123,6 +123,12 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const floa
         for (int q = 0; q < 16; ++q)
             buf[fft_pad(base + 16 * q)] = v[q];
     }
+    // pass 2's twiddles are requested in front of the barrier (v is dead here: the registers are free), so that they arrive while the
+    // workgroup waits for its slowest wave instead of behind the fragment reads
+    float2 w2[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r)
+        w2[r] = tw2[r * 256 + j];
     __syncthreads();
     // pass 2 (Ns = 256): k = j, in-place per thread (reads and writes buf[j + 256*q])
     {
@@ -132,7 +138,7 @@ __device__ __forceinline__ void fft4096(float2 (&v)[16], float2 *buf, const floa
 #pragma unroll
         for (int r = 1; r < 16; ++r)
         {
-            float2 w = tw2[r * 256 + j];
+            const float2 w = w2[r];
             v[r] = cmul_tw(v[r], INV ? cconj(w) : w);
         }
         fft16<INV>(v);
