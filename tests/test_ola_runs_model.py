@@ -98,3 +98,30 @@ def test_a_different_order_of_the_terms_would_show():
     for f in reversed(range(T)):
         acc[f * HOP:f * HOP + NFFT] = acc[f * HOP:f * HOP + NFFT] + frames[f]
     assert not np.array_equal(acc[NFFT // 2:NFFT // 2 + n].view(np.uint32), reference_ola(frames, n).view(np.uint32))
+
+
+@pytest.mark.parametrize("T", [1, 4, 7, 9, 2584])
+def test_window_sum_square_repeats_with_the_hop_on_interior_blocks(T):
+    """wiener_istft_kernel takes the normalisation of an INTERIOR frame (hop blocks f .. f + 3 all complete: 3 <= f <= T - 4) from ONE
+    hop of the window sum-square kept in LDS (block 3 of the table) instead of reading the table per sample: the table (dsp.hpp:80-101 as
+    engine_init.h builds it -- frames in ascending order, w * w added in float32) must repeat with the hop, bit for bit, on every block
+    that all four of its frames reach (3 <= h <= T - 1); the edge blocks differ and keep the per-sample read."""
+    PI = np.float32(3.14159265359)
+    n = np.arange(NFFT, dtype=np.float32)
+    # dsp.hpp:61-78 in float32 (the device tables are built on the host with cosf; the bits of w do not matter for the property)
+    w = (np.float32(0.5) * (np.float32(1.0) - np.cos(np.float32(2.0) * PI * n / np.float32(NFFT), dtype=np.float32))).astype(np.float32)
+    w2 = w * w
+    nw = np.zeros(NFFT + HOP * (T - 1), np.float32)
+    for f in range(T):
+        nw[f * HOP:f * HOP + NFFT] = nw[f * HOP:f * HOP + NFFT] + w2
+    assert nw.size >= 4 * HOP  # the kernel reads block 3 whatever T is: in range
+    blocks = nw.reshape(-1, HOP)
+    interior = [h for h in range(blocks.shape[0]) if 3 <= h <= T - 1]
+    for h in interior:
+        assert np.array_equal(blocks[h].view(np.uint32), blocks[3].view(np.uint32)), h
+    if T >= 4:
+        assert not np.array_equal(blocks[2], blocks[3]) and not np.array_equal(blocks[T], blocks[3])  # the edges are different tables
+    # the frames the kernel calls interior use only interior blocks
+    for f in range(T):
+        if f >= 3 and f + 3 <= T - 1:
+            assert all(h in interior for h in range(f, f + 4))

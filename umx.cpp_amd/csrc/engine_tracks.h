@@ -131,9 +131,21 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
         for (int t = 0; t < 4; ++t)
             UMX_HIP_CHECK(hipMemset(tb_.out[t], 0, sizeof(float) * 2 * (size_t)L2[ln]));
         UMX_HIP_CHECK(hipMemset(tb_.sumw, 0, sizeof(float) * (size_t)L2[ln]));
-        UMX_HIP_CHECK(hipMemcpy(tb_.in + 2 * (size_t)lead[ln], audio_host[ln], sizeof(float) * 2 * (size_t)length[ln], hipMemcpyHostToDevice));
     }
     UMX_HIP_CHECK(hipDeviceSynchronize());
+    // The track goes up segment by segment (round 6): a call needs the samples up to the end of its last segment, and the rest of a
+    // pageable upload (14 GB/s: 15 ms for ten minutes of stereo) runs while the device is busy with the segments before it -- the
+    // slots' streams do not wait for the null stream, and launches are queued ahead of the copy.
+    long long uploaded[LSTMB_MAX_TRACKS] = {}; // host samples of each track already on the device
+    auto upload_until = [&](int ti, long long padded_end) -> hipError_t { // samples of the padded signal below `padded_end` must be there
+        const long long want = std::min<long long>(length[ti], padded_end - lead[ti]);
+        if (want <= uploaded[ti])
+            return hipSuccess;
+        const hipError_t e = hipMemcpy(trk[ti].in + 2 * ((size_t)lead[ti] + (size_t)uploaded[ti]), audio_host[ti] + 2 * (size_t)uploaded[ti],
+                                       sizeof(float) * 2 * (size_t)(want - uploaded[ti]), hipMemcpyHostToDevice);
+        uploaded[ti] = want;
+        return e;
+    };
 
     const float total_reps = std::ceil((float)L2max / (float)stride); // umx.cpp:208 (of the longest track)
     float done = 0.f;
@@ -168,6 +180,12 @@ int umx_hip_ctx::tracks_once(int nt, const float *const *audio_host, const int *
                 seg_off[ln] = (int)so;
                 ain[ln] = trk[ti].in + 2 * (size_t)so;
                 nn[ln] = std::min(N, L2[ti] - (int)so);
+                if (upload_until(ti, so + N) != hipSuccess)
+                {
+                    cleanup();
+                    set_error("track: upload failed");
+                    return UMX_ERR_HIP;
+                }
                 for (int t = 0; t < 4; ++t)
                     outs[4 * ln + t] = trk[ln].seg[si][t];
             }
