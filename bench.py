@@ -540,7 +540,7 @@ def main():
             "value": round(value, 2), "unit": "x realtime", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (activations as 2 x fp16 planes of the power-of-two-scaled row, integer weights exact in fp16, f32 accumulate on the fp16 matrix cores; fp32-grade: 1.4-2.2x the error of an fp32 evaluation, profiles/r06_v1_accuracy_vs_float64.txt)" if batched else "f32 (dense stack: operands as 3 bf16 terms on the bf16 matrix cores, f32 accumulate; recurrence on the fp32 vector pipe)",
+            "dtype": "f32 (activations as 2 x fp16 planes of the power-of-two-scaled row, integer weights exact in fp16, f32 accumulate on the fp16 matrix cores; fp32-grade: 1.4-2.2x the error of an fp32 evaluation, profiles/r06_v2_accuracy_vs_float64.txt)" if batched else "f32 (dense stack: operands as 3 bf16 terms on the bf16 matrix cores, f32 accumulate; recurrence on the fp32 vector pipe)",
             "data": "synthetic",
             "ms_per_step_min": round(min(serial), 3), "ms_per_step_median": round(float(np.median(serial)), 3),
             "ms_per_step_note": f"min / median over {len(serial)} further steps run one at a time (sync after each); ms_per_step is the mean of the timed region",
