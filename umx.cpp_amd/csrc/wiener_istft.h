@@ -2,20 +2,23 @@
 // the filtered spectrograms y [4][2][T][2049] complex (339 MB per 60 s segment, written by one kernel and read back by
 // the next) never touch HBM.
 //
-// One workgroup per frame, 1024 threads.
-//   phase 1  thread t handles bins b = t + 1024 q (2049 bins, 2-3 per thread): loads the mixture (2 channels), the four
-//            targets' masks (x 2 channels; x |X| = the target magnitudes) and the four R (16 bytes each), forms what does not depend on the output
+// One 1024-thread workgroup per RUN of consecutive frames of a lane (one workgroup per CU: 158 of its 160 KB of LDS); per frame:
+//   phase 1  thread t handles bins b = t + 1024 q (2049 bins, 2-3 per thread): the mixture (2 channels), the four targets' masks
+//            (x 2 channels; x |X| = the target magnitudes) and the four R (16 bytes each); forms what does not depend on the output
 //            source -- mixture over max_abs, the four PSDs, the inverse of Cxx (wiener.cpp:270-341) -- and then, for each
 //            source, y_s = G_s x (wiener.cpp:343-400), written straight into the INPUT of that source's inverse FFT in
 //            LDS: one complex 4096-point transform per source carries the left channel in its real and the right channel
 //            in its imaginary part (stft_kernels.h), so bin b fills two slots:
 //                in[b]        = L[b] + i R[b]                  b <= 2048
 //                in[4096 - b] = conj(L[b]) + i conj(R[b])      0 < b < 2048
-//   phase 2  the four 256-thread groups transform the four sources side by side (4 x 34 KB of LDS), apply the
-//            reference's per-sample weight (dsp.cpp:248-256) and store the frames.
-// 16 waves per CU hide the latencies of both phases (a 256-thread version holding nine bins per thread in registers ran
-// at one wave per SIMD and was no faster than the two kernels it replaced).  Per frame: 98 KB of spectrogram /
-// magnitudes and 131 KB of R (L2-resident) in, 131 KB of frames out, against 229 + 131 KB in and 131 + 131 KB out.
+//   phase 2  the four 256-thread groups transform the four sources side by side (4 x 34 KB of LDS); the last pass stays in registers;
+//   phase 3  the reference's per-sample weight (dsp.cpp:248-256) and the overlap-add across the run's frames in registers: a stem
+//            sample is stored once (the run's first three hop blocks: wiener_ola_edges_kernel).
+// What a frame costs is waiting, not arithmetic: sixteen waves reach every phase together, vector memory returns in order and
+// the CU has one address path for it.  Hence: the next frame's first bin is requested under phase 3 (which itself loads nothing behind that
+// request: window and the interior hops' sum-square sit in LDS), the second bin and R at the top of phase 1, the second pass's twiddles in
+// LDS, the last pass's requested in front of the barrier.  Per frame: 98 KB of spectrogram / magnitudes and 131 KB of R (L2-resident) in,
+// 32 KB of stems out.
 // WIENER = false is BASELINE config 2: y_s = mag_s * exp(i arg X) (wiener.cpp:96-109 only).
 #pragma once
 #include "stft_kernels.h"
