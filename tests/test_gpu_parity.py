@@ -322,18 +322,20 @@ def test_fused_wiener_istft_equals_the_unfused_kernels_bitwise(pkg, model_small,
     import torch
     torch.zeros(1).cuda()
     path, om, targets = model_small
-    N = 40 * 1024
-    wave = pkg.ggml.synth_audio(N, 77)
-    for flags in (pkg.FLAG_DEBUG_TAPS, pkg.FLAG_DEBUG_TAPS | pkg.FLAG_NO_WIENER):
-        res = {}
-        for mode in ("stats4", "fused"):
-            monkeypatch.setenv("UMX_WIENER", mode)
-            eng = pkg.Engine(targets, 128, N)
-            res[mode] = (eng.infer_segment(wave, flags), [eng.tap("y", t) for t in range(4)])
-            eng.close()
-        for t in range(4):
-            assert np.array_equal(res["fused"][0][t], res["stats4"][0][t])
-            assert np.array_equal(res["fused"][1][t], res["stats4"][1][t])
+    # 41 frames: five runs of nine -- frames kept at a run's start, the next frame's inputs requested under the overlap-add, interior frames
+    # (window sum-square from LDS) and the three edge frames at either end, a last STFT run of one frame; 6 frames: one run, no interior frame
+    for N in (40 * 1024, 5 * 1024):
+        wave = pkg.ggml.synth_audio(N, 77)
+        for flags in (pkg.FLAG_DEBUG_TAPS, pkg.FLAG_DEBUG_TAPS | pkg.FLAG_NO_WIENER):
+            res = {}
+            for mode in ("stats4", "fused"):
+                monkeypatch.setenv("UMX_WIENER", mode)
+                eng = pkg.Engine(targets, 128, N)
+                res[mode] = (eng.infer_segment(wave, flags), [eng.tap("y", t) for t in range(4)])
+                eng.close()
+            for t in range(4):
+                assert np.array_equal(res["fused"][0][t], res["stats4"][0][t]), (N, flags, t)
+                assert np.array_equal(res["fused"][1][t], res["stats4"][1][t]), (N, flags, t)
 
 
 def test_wiener_bin_arithmetic_against_a_reference_order_float64_restatement(pkg):
